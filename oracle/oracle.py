@@ -1,0 +1,170 @@
+"""ctypes front-end for the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Two libraries can sit behind it:
+
+  * ``port``      -- oracle/libgpuar_oracle.so, the plain-C restatement in
+                     oracle/arcodec_oracle.c (always available; built by make).
+  * ``reference`` -- oracle/_ref/libgpuar_ref.so, the reference's unmodified
+                     arCompress/arDecompress (oracle/build_ref.sh; prebuilt file
+                     travels to the GPU box, /root/reference does not).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PACKET_IN = 8192
+PACKET_SLOT = 8704
+HEADER_LEN = 20
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (gcc) and, when /root/reference exists, oracle/_ref."""
+    so = os.path.join(HERE, "libgpuar_oracle.so")
+    src = os.path.join(HERE, "arcodec_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-Wall", "-shared", "-fPIC", "-o", so, src])
+    ref_so = os.path.join(HERE, "_ref", "libgpuar_ref.so")
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_u8p)
+
+
+class _Codec:
+    kind = "?"
+
+    def __init__(self, lib, prefix):
+        self._lib = lib
+        p = prefix
+        self._enc_pkt = getattr(lib, p + "encode_packet")
+        self._enc_pkt.restype = C.c_size_t
+        self._enc_pkt.argtypes = [_u8p, C.c_uint16, _u8p]
+        self._enc_stream = getattr(lib, p + "encode_stream")
+        self._enc_stream.restype = C.c_size_t
+        self._enc_stream.argtypes = [_u8p, C.c_size_t, _u8p]
+
+    # -- packets -----------------------------------------------------------
+    def encode_packet(self, data) -> bytes:
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+        assert a.size <= PACKET_IN
+        src = np.zeros(max(a.size, 1) + 32, dtype=np.uint8)
+        src[:a.size] = a
+        out = np.zeros(2 * PACKET_IN + 64, dtype=np.uint8)
+        n = self._enc_pkt(_ptr(src), a.size, _ptr(out))
+        return out[:n].tobytes()
+
+    # -- streams (packets back to back, no 20-byte header) -----------------
+    def encode_stream(self, data) -> np.ndarray:
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+        npk = (a.size + PACKET_IN - 1) // PACKET_IN
+        out = np.empty(npk * PACKET_SLOT + 64, dtype=np.uint8)
+        src = np.zeros(a.size + 32, dtype=np.uint8)
+        src[:a.size] = a
+        n = self._enc_stream(_ptr(src), a.size, _ptr(out))
+        return out[:n].copy()
+
+
+class PortOracle(_Codec):
+    kind = "port"
+
+    def __init__(self):
+        build()
+        lib = C.CDLL(os.path.join(HERE, "libgpuar_oracle.so"))
+        super().__init__(lib, "oracle_")
+        lib.oracle_decode_packet.restype = C.c_size_t
+        lib.oracle_decode_packet.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t]
+        lib.oracle_decode_stream.restype = C.c_size_t
+        lib.oracle_decode_stream.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t]
+        lib.oracle_encode_slots.restype = C.c_size_t
+        lib.oracle_encode_slots.argtypes = [_u8p, C.c_size_t, _u8p]
+        lib.oracle_decode_slots.restype = None
+        lib.oracle_decode_slots.argtypes = [_u8p, C.c_size_t, _u8p]
+
+    def decode_packet(self, pkt: bytes) -> bytes:
+        a = np.frombuffer(pkt, dtype=np.uint8).copy()
+        out = np.zeros(PACKET_IN, dtype=np.uint8)
+        n = self._lib.oracle_decode_packet(_ptr(a), a.size, _ptr(out), out.size)
+        return out[:n].tobytes()
+
+    def decode_stream(self, stream, n_out: int) -> np.ndarray:
+        a = np.ascontiguousarray(stream)
+        out = np.zeros(n_out + PACKET_IN, dtype=np.uint8)
+        n = self._lib.oracle_decode_stream(_ptr(a), a.size, _ptr(out), out.size)
+        if n == C.c_size_t(-1).value:
+            raise ValueError("malformed packet stream")
+        return out[:n].copy()
+
+    def encode_slots(self, data: np.ndarray):
+        """Fixed 8704-byte slots as garCompress lays them out; returns (slots, sum clen)."""
+        a = np.ascontiguousarray(data)
+        npk = (a.size + PACKET_IN - 1) // PACKET_IN
+        slots = np.zeros(npk * PACKET_SLOT, dtype=np.uint8)
+        total = self._lib.oracle_encode_slots(_ptr(a), a.size, _ptr(slots))
+        if total == C.c_size_t(-1).value:
+            raise OverflowError("a packet outgrew its 8704-byte slot")
+        return slots, total
+
+    def decode_slots(self, slots: np.ndarray, n_packets: int) -> np.ndarray:
+        a = np.ascontiguousarray(slots)
+        out = np.zeros(n_packets * PACKET_IN, dtype=np.uint8)
+        self._lib.oracle_decode_slots(_ptr(a), n_packets, _ptr(out))
+        return out
+
+
+class ReferenceOracle(_Codec):
+    kind = "reference"
+
+    def __init__(self):
+        build()
+        path = os.path.join(HERE, "_ref", "libgpuar_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        lib = C.CDLL(path)
+        super().__init__(lib, "ref_")
+        lib.ref_decode_packet.restype = C.c_size_t
+        lib.ref_decode_packet.argtypes = [_u8p, C.c_size_t, _u8p]
+        lib.ref_decode_stream.restype = C.c_size_t
+        lib.ref_decode_stream.argtypes = [_u8p, C.c_size_t, _u8p]
+
+    def decode_packet(self, pkt: bytes) -> bytes:
+        a = np.frombuffer(pkt, dtype=np.uint8).copy()
+        out = np.zeros(65536 + 64, dtype=np.uint8)
+        n = self._lib.ref_decode_packet(_ptr(a), a.size, _ptr(out))
+        return out[:n].tobytes()
+
+    def decode_stream(self, stream, n_out: int) -> np.ndarray:
+        a = np.ascontiguousarray(stream)
+        out = np.zeros(n_out + PACKET_IN + 64, dtype=np.uint8)
+        n = self._lib.ref_decode_stream(_ptr(a), a.size, _ptr(out))
+        if n == C.c_size_t(-1).value:
+            raise ValueError("malformed packet stream")
+        return out[:n].copy()
+
+
+def have_reference() -> bool:
+    return os.path.exists(os.path.join(HERE, "_ref", "libgpuar_ref.so"))
+
+
+def best():
+    """The strongest checker available: the reference build if present, else the port."""
+    return ReferenceOracle() if have_reference() else PortOracle()
+
+
+# -- container (20-byte header) as the reference writes it -------------------
+# src/file_header.hpp:19-36,61-72; zeros where the reference leaves stack garbage.
+def gip_header(n_uncompressed: int, n_stream: int) -> bytes:
+    h = bytearray(HEADER_LEN)
+    h[0:3] = bytes([0, 1, 0])
+    h[4:12] = int(n_uncompressed).to_bytes(8, "little")
+    h[12:20] = int(HEADER_LEN + n_stream).to_bytes(8, "little")
+    return bytes(h)
