@@ -1,0 +1,489 @@
+// gpuar_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the GPUAR packet codec.
+//
+// One lane = one packet, 64 packets per wavefront, one wavefront per
+// workgroup.  What the reference does with a 32-thread CUDA block, a 516-byte
+// Fenwick tree per thread in shared memory and bit-at-a-time loops
+// (/root/reference/src/gpuar_kernel.cu:894-934, 205-238, 321-367, 787-836) is
+// re-derived here for a 64-wide wavefront:
+//
+//  * Model: per lane a complete binary "left-count" tree over the 256
+//    symbols (255 u16 nodes, heap order) in LDS, laid out node-major /
+//    lane-minor so that whatever symbol each lane touches, lane l always hits
+//    LDS bank (l & 31) -- no bank conflicts by construction.  One root-to-leaf
+//    walk (8 reads + 8 writes, addresses known from the symbol alone) yields
+//    cumLo, cumHi AND performs the count update; the decoder's symbol search
+//    is the same walk steered by the code value.  Bit-exact with the
+//    reference's Fenwick model because both are exact integer prefix sums of
+//    the same counts.
+//  * Range update: the divisor `total = 256 + i` is wave-uniform, so the two
+//    divisions per symbol become mul-hi by a reciprocal read with scalar
+//    loads from a compile-time table (exact for every numerator < 2^30).
+//  * Renormalisation in closed form (count-leading-zeros instead of the
+//    reference's data-dependent loop): e matching bits, then u underflow
+//    bits, never interleaved (proof sketch at renorm_split()).
+//  * Bits leave through a per-lane 64-bit accumulator, one big-endian dword
+//    store per 32 bits.
+//
+// No MFMA: this is integer, bit-serial work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gpuar_hip.h"
+
+#include "lane_codec.h"
+
+namespace gpuar {
+
+__constant__ RecipTable g_recip = RecipTable();
+__device__ uint32_t g_status = 0;
+
+// Lane's column in a tree row: lanes l and l+32 share a dword (low/high half),
+// so the 32 lanes of each LDS lane-group hit 32 distinct banks whatever node
+// each of them addresses.
+__device__ __forceinline__ uint32_t lane_column(uint32_t lane) {
+    return ((lane & 31u) << 1) | (lane >> 5);
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = __shfl_xor(v, off);
+        v = other > v ? other : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) {
+    if (avail >= 16) return *reinterpret_cast<const uint4 *>(p);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (size_t b = 0; b < avail; ++b) w[b >> 2] |= static_cast<uint32_t>(p[b]) << (8u * (b & 3u));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Encode: replaces garCompress + arCompress (src/gpuar_kernel.cu:894-914, 487-531)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLanes)
+encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
+    __shared__ uint16_t tree[kTreeRows * kLanes];  // 32 KiB: 255 nodes x 64 lanes x u16
+
+    const uint32_t lane = threadIdx.x;
+    const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
+    const bool live = packet < n_packets;
+    const size_t start = packet * kPacket;
+    const uint32_t len = live ? static_cast<uint32_t>(size - start < kPacket ? size - start : kPacket) : 0u;
+    const uint8_t *in = src + (live ? start : 0);
+    uint8_t *slot = dst + (live ? packet : 0) * static_cast<size_t>(kSlot);
+
+    EncoderLane<kLanes> enc;
+    enc.open(tree + lane_column(lane), slot);
+
+    // wave-uniform trip count: every lane but (possibly) the file's last packet has 8192 symbols
+    const uint32_t len_max = wave_max(len);
+
+    uint4 chunk = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
+    for (uint32_t base = 0; base < len_max; base += 16) {
+        const uint4 cur = chunk;
+        if (base + 16 < len) chunk = load16_guarded(in + base + 16, len - (base + 16));
+        const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t word = words[q];
+#pragma unroll 1
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t i = base + 4u * q + b;        // wave-uniform symbol index
+                if (i >= len_max) break;
+                const Recip rc = g_recip.r[i];               // scalar load: total = 256 + i
+                const uint32_t x = word & 0xFFu;
+                word >>= 8;
+                if (i < len) enc.step(x, i, rc);
+            }
+        }
+    }
+
+    if (live) {
+        bool overflowed;
+        enc.finish(slot, len, overflowed);
+        if (overflowed) atomicOr(&g_status, GPUAR_STATUS_SLOT_OVERFLOW);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Decode: replaces garDecompress + arDecompress (:916-934, 848-892)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void decode_wave(uint16_t *col, const uint8_t *pkt, const uint8_t *limit,
+                                            uint8_t *out, bool live) {
+    DecoderLane<kLanes> dec;
+    dec.open(col, pkt, limit, live);
+    const uint32_t len_max = wave_max(dec.ulen);
+    for (uint32_t i = 0; i < len_max; ++i) {
+        const Recip rc = g_recip.r[i];
+        if (i < dec.ulen) dec.step(i, rc, out);
+    }
+    if (live) {
+        dec.finish(out);
+        if (dec.bad) atomicOr(&g_status, GPUAR_STATUS_BAD_PACKET);
+    }
+}
+
+__global__ void __launch_bounds__(kLanes)
+decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
+    __shared__ uint16_t tree[kTreeRows * kLanes];
+    const uint32_t lane = threadIdx.x;
+    const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
+    const bool live = packet < n_packets;
+    const uint8_t *pkt = slots + (live ? packet : 0) * static_cast<size_t>(kSlot);
+    decode_wave(tree + lane_column(lane), pkt, pkt + kSlot, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+}
+
+// Decode from a back-to-back packet stream (the bytes after the 20-byte .gip
+// header): lane p starts at stream + offsets[p].
+__global__ void __launch_bounds__(kLanes)
+decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offsets,
+                     uint32_t n_packets, uint8_t *__restrict__ out) {
+    __shared__ uint16_t tree[kTreeRows * kLanes];
+    const uint32_t lane = threadIdx.x;
+    const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
+    const bool live = packet < n_packets;
+    const uint8_t *pkt = stream + (live ? offsets[packet] : 0);
+    const uint8_t *limit = stream + offsets[n_packets];
+    decode_wave(tree + lane_column(lane), pkt, limit, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+}
+
+// ---------------------------------------------------------------------------
+// Compaction: exclusive scan of the packet lengths, then a gather of the
+// defined bytes of every slot into one back-to-back stream.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScanThreads = 256;
+constexpr uint32_t kScanItems = 16;                        // packets per thread
+constexpr uint32_t kScanTile = kScanThreads * kScanItems;  // 4096 packets per block
+constexpr uint32_t kScanMaxBlocks = 4096;                  // 16 Mi packets = 128 GiB of input per call
+__device__ uint64_t g_tile_prefix[kScanMaxBlocks];
+
+__device__ __forceinline__ uint32_t slot_clen(const uint8_t *slots, size_t p) {
+    return *reinterpret_cast<const uint16_t *>(slots + p * kSlot);
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &block_total) {
+    __shared__ uint32_t wave_sums[kScanThreads / kLanes];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t other = __shfl_up(incl, off);
+        if (lane >= static_cast<uint32_t>(off)) incl += other;
+    }
+    if (lane == 63u) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kScanThreads / kLanes; ++w) {
+        const uint32_t s = wave_sums[w];
+        before += (w < wave) ? s : 0u;
+        total += s;
+    }
+    __syncthreads();
+    block_total = total;
+    return before + incl - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+scan_tile_sums_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets) {
+    const size_t first = static_cast<size_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kScanItems; ++k)
+        if (first + k < n_packets) sum += slot_clen(slots, first + k);
+    uint32_t total;
+    block_exclusive_scan(sum, total);
+    if (threadIdx.x == 0) g_tile_prefix[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+scan_tile_prefix_kernel(uint32_t n_tiles) {   // one block; n_tiles <= 4096
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
+        const uint32_t t = base + threadIdx.x;
+        const uint64_t v = t < n_tiles ? g_tile_prefix[t] : 0;
+        // tile sums fit 32 bits (4096 * 8704), prefixes need 64
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(static_cast<uint32_t>(v), total);
+        const uint64_t start = carry;
+        if (t < n_tiles) g_tile_prefix[t] = start + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = start + total;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+scan_offsets_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint64_t *__restrict__ offsets) {
+    const size_t first = static_cast<size_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+    uint32_t lens[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) {
+        lens[k] = (first + k < n_packets) ? slot_clen(slots, first + k) : 0u;
+        sum += lens[k];
+    }
+    uint32_t total;
+    uint64_t run = g_tile_prefix[blockIdx.x] + block_exclusive_scan(sum, total);
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) {
+        if (first + k < n_packets) offsets[first + k] = run;
+        run += lens[k];
+        if (first + k + 1 == n_packets) offsets[n_packets] = run;
+    }
+}
+
+// One wavefront moves one packet: 16 B per lane per step, destination-aligned
+// stores, source read through byte-exact unaligned loads.
+__global__ void __launch_bounds__(256)
+gather_kernel(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ offsets, uint32_t n_packets,
+              uint8_t *__restrict__ stream) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t packet = static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (packet >= n_packets) return;
+    const uint8_t *src = slots + packet * kSlot;
+    const uint64_t off = offsets[packet];
+    const uint32_t len = static_cast<uint32_t>(offsets[packet + 1] - off);
+    uint8_t *dst = stream + off;
+    // head: bytes up to the first 16-byte boundary of dst
+    uint32_t head = static_cast<uint32_t>((16u - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
+    if (head > len) head = len;
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t body = (len - head) & ~15u;
+    for (uint32_t at = lane * 16u; at < body; at += 64u * 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + at, 16);
+        *reinterpret_cast<uint4 *>(dst + head + at) = v;
+    }
+    const uint32_t tail = len - head - body;
+    if (lane < tail) dst[head + body + lane] = src[head + body + lane];
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic input streams; bench/test support.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix_word(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + k * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+generate_uniform_kernel(uint64_t seed, uint64_t first_word, size_t n, uint8_t *__restrict__ out) {
+    const size_t w = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
+    const size_t at = w * 8u;
+    if (at >= n) return;
+    const uint64_t v = splitmix_word(seed, first_word + w + 1u);
+    if (at + 8u <= n) {
+        *reinterpret_cast<uint64_t *>(out + at) = v;
+    } else {
+        for (size_t b = 0; at + b < n; ++b) out[at + b] = static_cast<uint8_t>(v >> (8u * b));
+    }
+}
+
+struct ZipfTable {
+    uint32_t cum[256];
+    uint8_t sym[256];
+};
+
+// K ranks, weight floor(2^24 / r); each thread makes 8 bytes from 4 words
+__global__ void __launch_bounds__(256)
+generate_zipf_kernel(uint64_t seed, uint64_t first_word, size_t n, uint8_t *__restrict__ out,
+                     ZipfTable table, uint32_t K) {
+    __shared__ uint32_t cum[256];
+    __shared__ uint8_t sym[256];
+    cum[threadIdx.x] = threadIdx.x < K ? table.cum[threadIdx.x] : 0xFFFFFFFFu;
+    sym[threadIdx.x] = table.sym[threadIdx.x];
+    __syncthreads();
+    const uint64_t W = table.cum[K - 1];
+    const size_t g = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;  // group of 4 words = 8 bytes
+    const size_t at = g * 8u;
+    if (at >= n) return;
+    uint64_t packed = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t word = splitmix_word(seed, first_word + g * 4u + j + 1u);
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint64_t u = h ? (word >> 32) : (word & 0xFFFFFFFFull);
+            const uint32_t t = static_cast<uint32_t>((u * W) >> 32);
+            uint32_t lo = 0, hi = K;   // first index with cum[idx] > t
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cum[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            packed |= static_cast<uint64_t>(sym[lo]) << (8u * (2u * j + h));
+        }
+    }
+    if (at + 8u <= n) {
+        *reinterpret_cast<uint64_t *>(out + at) = packed;
+    } else {
+        for (size_t b = 0; at + b < n; ++b) out[at + b] = static_cast<uint8_t>(packed >> (8u * b));
+    }
+}
+
+}  // namespace gpuar
+
+// ===========================================================================
+// C ABI (include/gpuar_hip.h)
+// ===========================================================================
+namespace {
+
+thread_local int t_last_error = GPUAR_OK;
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_launch() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gpuar_hip_packet_count(size_t n_bytes) { return (n_bytes + GPUAR_PACKET_BYTES - 1) / GPUAR_PACKET_BYTES; }
+
+int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void *stream) {
+    if (n_bytes == 0) return GPUAR_OK;
+    if (!d_in || !d_slots) return GPUAR_ERR_ARGUMENT;
+    if (!aligned16(d_in) || !aligned16(d_slots)) return GPUAR_ERR_ALIGNMENT;
+    const size_t n_packets = gpuar_hip_packet_count(n_bytes);
+    if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
+    const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    gpuar::encode_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+        d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
+    return check_launch();
+}
+
+int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, void *stream) {
+    if (n_packets == 0) return GPUAR_OK;
+    if (!d_slots || !d_out || n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
+    if (!aligned16(d_slots) || !aligned16(d_out)) return GPUAR_ERR_ALIGNMENT;
+    const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    gpuar::decode_slots_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+        d_slots, static_cast<uint32_t>(n_packets), d_out);
+    return check_launch();
+}
+
+int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_stream, uint64_t *d_offsets, void *stream) {
+    if (!d_offsets) return GPUAR_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_packets == 0) {
+        const hipError_t e = hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s);
+        return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
+    }
+    if (!d_slots || !d_stream) return GPUAR_ERR_ARGUMENT;
+    if (!aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_offsets) & 7u)) return GPUAR_ERR_ALIGNMENT;
+    const size_t tiles = (n_packets + gpuar::kScanTile - 1) / gpuar::kScanTile;
+    if (tiles > gpuar::kScanMaxBlocks) return GPUAR_ERR_ARGUMENT;
+    const uint32_t np = static_cast<uint32_t>(n_packets);
+    gpuar::scan_tile_sums_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np);
+    gpuar::scan_tile_prefix_kernel<<<1, gpuar::kScanThreads, 0, s>>>(static_cast<uint32_t>(tiles));
+    gpuar::scan_offsets_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, d_offsets);
+    gpuar::gather_kernel<<<static_cast<uint32_t>((n_packets + 3) / 4), 256, 0, s>>>(d_slots, d_offsets, np, d_stream);
+    return check_launch();
+}
+
+int gpuar_hip_decode_stream(const uint8_t *d_stream, const uint64_t *d_offsets, size_t n_packets,
+                            uint8_t *d_out, void *stream) {
+    if (n_packets == 0) return GPUAR_OK;
+    if (!d_stream || !d_offsets || !d_out || n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
+    if (!aligned16(d_out) || (reinterpret_cast<uintptr_t>(d_stream) & 3u)) return GPUAR_ERR_ALIGNMENT;
+    const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    gpuar::decode_stream_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+        d_stream, d_offsets, static_cast<uint32_t>(n_packets), d_out);
+    return check_launch();
+}
+
+int gpuar_hip_status(uint32_t *flags) {
+    if (!flags) return GPUAR_ERR_ARGUMENT;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return static_cast<int>(e);
+    uint32_t v = 0;
+    e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(gpuar::g_status), sizeof v);
+    if (e != hipSuccess) return static_cast<int>(e);
+    const uint32_t zero = 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(gpuar::g_status), &zero, sizeof zero);
+    *flags = v;
+    return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
+}
+
+int gpuar_hip_last_error(void) {
+    const int e = t_last_error;
+    t_last_error = GPUAR_OK;
+    return e;
+}
+
+const char *gpuar_hip_error_string(int code) {
+    switch (code) {
+        case GPUAR_OK: return "ok";
+        case GPUAR_ERR_ALIGNMENT: return "device pointer is not suitably aligned (16 bytes)";
+        case GPUAR_ERR_ARGUMENT: return "invalid argument";
+        case GPUAR_ERR_NO_DEVICE: return "no HIP device";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown gpuar error";
+    }
+}
+
+const char *gpuar_hip_version(void) { return "gpuar-hip 0.1 gfx950"; }
+
+int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8_t *d_out, void *stream) {
+    if (n == 0) return GPUAR_OK;
+    if (!d_out || (offset & 7u) || kind < 0 || kind > 2) return GPUAR_ERR_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(d_out) & 7u) return GPUAR_ERR_ALIGNMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t groups = (n + 7) / 8;
+    const uint32_t blocks = static_cast<uint32_t>((groups + 255) / 256);
+    if (kind == 0) {
+        gpuar::generate_uniform_kernel<<<blocks, 256, 0, s>>>(seed, offset / 8, n, d_out);
+    } else {
+        static const char rank[] =
+            " etaoinshrdlcumwfgypbvkjxqz\n.,ETAOINSHRDLCUMWFGYPBVKJXQZ0123456789-'\"()/:;=_<>[]{}!?#$%&*+@\\^`|~";
+        gpuar::ZipfTable t;
+        memset(&t, 0, sizeof t);
+        const uint32_t K = kind == 1 ? 256u : 96u;
+        uint32_t run = 0;
+        for (uint32_t r = 1; r <= K; ++r) {
+            run += (1u << 24) / r;
+            t.cum[r - 1] = run;
+            t.sym[r - 1] = kind == 1 ? static_cast<uint8_t>(((r - 1) * 167u + 13u) & 255u) : static_cast<uint8_t>(rank[r - 1]);
+        }
+        gpuar::generate_zipf_kernel<<<blocks, 256, 0, s>>>(seed, offset / 2, n, d_out, t, K);
+    }
+    return check_launch();
+}
+
+// ---- reference-named shims (src/gpuar.h:74,77,78) --------------------------
+void initConstantRange(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        t_last_error = GPUAR_ERR_NO_DEVICE;
+        return;
+    }
+    (void)hipFree(nullptr);  // forces context creation on the current device
+}
+
+void garCompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks) {
+    (void)numBlocks;
+    const int e = gpuar_hip_encode(source, size, destination, nullptr);
+    if (e != GPUAR_OK) {
+        t_last_error = e;
+        fprintf(stderr, "garCompressExecutor: %s\n", gpuar_hip_error_string(e));
+    }
+}
+
+void garDecompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks) {
+    (void)numBlocks;
+    const int e = gpuar_hip_decode(source, size / GPUAR_SLOT_BYTES, destination, nullptr);
+    if (e != GPUAR_OK) {
+        t_last_error = e;
+        fprintf(stderr, "garDecompressExecutor: %s\n", gpuar_hip_error_string(e));
+    }
+}
+
+}  // extern "C"

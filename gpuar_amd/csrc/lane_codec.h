@@ -1,0 +1,413 @@
+// lane_codec.h -- what ONE lane does for ONE packet, written once.
+//
+// Compiled by hipcc into the gfx950 kernels (gpuar_kernels.hip), where 64
+// lanes run it in lock step over 64 packets.  The same source also compiles
+// with a host compiler (tests/lane_emulation.cpp) so the closed forms below
+// can be checked against the oracle on a machine without a GPU; that host
+// build is a test harness only and is not linked into any product library.
+//
+// Semantics follow SURVEY.md section 8(a); reference lines are cited at each
+// function (/root/reference/src/gpuar_kernel.cu unless noted).
+#ifndef GPUAR_LANE_CODEC_H
+#define GPUAR_LANE_CODEC_H
+
+#include <stdint.h>
+#include <string.h>
+
+#include "gpuar_hip.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define GPUAR_LANE __device__ __forceinline__
+#define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
+#define GPUAR_MULHI(a, b) __umulhi((a), (b))
+#define GPUAR_RCP_QUOT(num, den) \
+    static_cast<uint32_t>(__uint2float_rz(num) * __frcp_rn(__uint2float_rn(den)))
+#else
+#define GPUAR_LANE inline
+#define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
+#define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
+// host stand-in for the estimate only: deliberately off by one both ways on a
+// rotating schedule, so the exact correction that follows it is exercised
+#define GPUAR_RCP_QUOT(num, den) \
+    (static_cast<uint32_t>((num) / (den)) + (((num) % 3u) == 0u ? 1u : (((num) % 3u) == 1u && (num) >= (den) ? 0xFFFFFFFFu : 0u)))
+#endif
+
+namespace gpuar {
+
+constexpr uint32_t kPacket = GPUAR_PACKET_BYTES;   // 8192
+constexpr uint32_t kSlot = GPUAR_SLOT_BYTES;       // 8704
+constexpr uint32_t kHdr = GPUAR_PACKET_HEADER_BYTES;
+constexpr uint32_t kLanes = 64;
+constexpr uint32_t kTreeRows = 256;                // row 0 unused, rows 1..255 = heap nodes
+
+// ---------------------------------------------------------------------------
+// Exact division by the wave-uniform model total d = 256 + i, i in [0, 8192).
+// For n < 2^30 and 2^(l-1) < d <= 2^l:  floor(n/d) == (n * m) >> (30 + l)
+// with m = ceil(2^(30+l) / d) < 2^31  (Granlund & Montgomery, N = 30).
+// Numerators here are cum * range <= d * 65536 < 2^30 because the model total
+// never exceeds 256 + 8192 < 2^14 (the guard of src/compressor.cpp:13-16).
+// ---------------------------------------------------------------------------
+struct Recip {
+    uint32_t mul;
+    uint32_t shift;  // applied to the high 32 bits of n * mul
+};
+
+struct RecipTable {
+    Recip r[kPacket];
+    constexpr RecipTable() : r{} {
+        for (uint32_t i = 0; i < kPacket; ++i) {
+            const uint64_t d = 256u + i;
+            uint32_t l = 8;
+            while ((1ull << l) < d) ++l;
+            const uint64_t m = ((1ull << (30 + l)) + d - 1) / d;
+            r[i].mul = static_cast<uint32_t>(m);
+            r[i].shift = l - 2;  // (n*m) >> (30+l) == hi32(n*m) >> (l-2)
+        }
+    }
+};
+
+GPUAR_LANE uint32_t div_total(uint32_t n, Recip rc) { return GPUAR_MULHI(n, rc.mul) >> rc.shift; }
+
+// ---------------------------------------------------------------------------
+// Adaptive order-0 model: complete binary tree of "count of symbols in my left
+// subtree", heap order, one u16 per node.  `col` points at this lane's column;
+// consecutive nodes are `stride` u16 apart (64 on the GPU: node-major,
+// lane-minor, so every lane keeps to its own LDS bank).
+// Equivalent to the reference's Fenwick tree (getRange/update :215-238):
+// both give exact prefix sums of the same counts.
+// ---------------------------------------------------------------------------
+template <uint32_t kStride>
+struct ModelTree {
+    uint16_t *col;
+
+    // every symbol starts with count 1 (:403-419)
+    GPUAR_LANE void reset() {
+#pragma unroll 1
+        for (uint32_t node = 1; node < kTreeRows; ++node) {
+            const uint32_t depth = 31u - GPUAR_CLZ32(node);
+            col[node * kStride] = static_cast<uint16_t>(128u >> depth);
+        }
+    }
+
+    // Known symbol x: returns cumLo | cumHi << 16 (counts of symbols < x and
+    // <= x, before the update) and adds 1 to x's count.  cumHi = cumLo(x+1):
+    // the path of x+1 leaves the path of x at x's lowest zero bit and has only
+    // zero bits below it, so both sums run over x's own eight nodes.
+    GPUAR_LANE uint32_t encode_step(uint32_t x, uint32_t total) {
+        const uint32_t y = x + 1;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t node = (1u << k) | (x >> (8 - k));
+            const uint32_t left = col[node * kStride];
+            const uint32_t bx = (x >> (7 - k)) & 1u;
+            const uint32_t by = (y >> (7 - k)) & 1u;
+            acc += left * (bx | (by << 16));
+            col[node * kStride] = static_cast<uint16_t>(left + (bx ^ 1u));
+        }
+        return (x == 255u) ? ((acc & 0xFFFFu) | (total << 16)) : acc;
+    }
+
+    // Decoder: the symbol s with cum(s) <= target < cum(s+1)
+    // (getSymbolFromProbability :727-763), found and updated in one walk.
+    GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
+        uint32_t node = 1, t = target, below = 0, span = total;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t left = col[node * kStride];
+            const bool right = t >= left;
+            col[node * kStride] = static_cast<uint16_t>(left + (right ? 0u : 1u));
+            t -= right ? left : 0u;
+            below += right ? left : 0u;
+            span = right ? span - left : left;
+            node = 2u * node + (right ? 1u : 0u);
+        }
+        cum_lo = below;
+        cum_hi = below + span;
+        return node - 256u;
+    }
+};
+
+// Interval narrowing (applySymbolRange :256-299); 16-bit state in 32-bit registers.
+GPUAR_LANE void narrow(uint32_t &lo, uint32_t &hi, uint32_t cum_lo, uint32_t cum_hi, Recip rc) {
+    const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
+    const uint32_t up = div_total(cum_hi * range, rc);
+    const uint32_t dn = div_total(cum_lo * range, rc);
+    hi = (lo + up - 1u) & 0xFFFFu;
+    lo = (lo + dn) & 0xFFFFu;
+}
+
+// Closed form of the renormalisation loops (writeEncodedBits :321-367,
+// readEncodedBits :787-836).  The loop first shifts out e = clz16(lo ^ hi)
+// agreeing MSBs; after that the MSBs differ (lo: 0, hi: 1).  An underflow
+// shift leaves lo's MSB 0 and hi's MSB 1 again, so no "agree" case can follow
+// an underflow case: the loop is always e agree-shifts, then u underflow
+// shifts, u = length of the run from bit 14 down where lo has 1 and hi has 0.
+struct Renorm {
+    uint32_t e, u;
+};
+GPUAR_LANE Renorm renorm_split(uint32_t &lo, uint32_t &hi) {
+    Renorm r;
+    r.e = GPUAR_CLZ32(lo ^ hi) - 16u;            // 0..16 (16 when lo == hi)
+    const uint32_t lo1 = (lo << r.e) & 0xFFFFu;
+    const uint32_t hi1 = ((hi << r.e) | ((1u << r.e) - 1u)) & 0xFFFFu;
+    const uint32_t run = lo1 & ~hi1;             // underflow candidates, bit 14 downwards
+    r.u = GPUAR_CLZ32(~(run << 17));             // 0..15 leading ones of bits 14..0
+    lo = (lo1 << r.u) & 0x7FFFu;
+    hi = ((hi1 << r.u) | ((1u << r.u) - 1u) | 0x8000u) & 0xFFFFu;
+    return r;
+}
+
+GPUAR_LANE uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// ---------------------------------------------------------------------------
+// Bit sink: MSB-first bits -> big-endian dwords in the packet slot
+// (writeBit/putChar :76-84,128-151).  `body` is slot + 4, 4-byte aligned.
+// ---------------------------------------------------------------------------
+struct BitSink {
+    uint64_t acc;     // low `n` bits are pending output, oldest bit highest
+    uint32_t n;       // < 32 between calls
+    uint32_t pos;     // bytes already stored after the 4-byte packet header
+    uint8_t *body;
+    bool overflow;
+
+    GPUAR_LANE void open(uint8_t *b) {
+        acc = 0;
+        n = 0;
+        pos = 0;
+        body = b;
+        overflow = false;
+    }
+
+    GPUAR_LANE void put(uint32_t bits, uint32_t count) {  // count <= 32
+        acc = (acc << count) | bits;
+        n += count;
+        if (n >= 32u) {
+            n -= 32u;
+            const uint32_t word = static_cast<uint32_t>(acc >> n);
+            if (pos + 4u <= kSlot - kHdr) {
+                const uint32_t be = bswap32(word);
+                memcpy(body + pos, &be, 4);
+            } else {
+                overflow = true;
+            }
+            pos += 4u;
+        }
+    }
+
+    // `count` copies of `bit`; count is unbounded in principle
+    GPUAR_LANE void put_run(uint32_t bit, uint32_t count) {
+        const uint32_t ones = 0u - bit;
+        while (count >= 32u) {
+            put(ones, 32u);
+            count -= 32u;
+        }
+        if (count) put(ones & ((1u << count) - 1u), count);
+    }
+
+    // zero-pad to a byte boundary and store the tail (writeClose :430-439);
+    // returns the body length in bytes
+    GPUAR_LANE uint32_t close() {
+        const uint32_t tail_bytes = (n + 7u) >> 3;
+        const uint32_t word = n ? static_cast<uint32_t>(acc << (32u - n)) : 0u;
+        for (uint32_t b = 0; b < tail_bytes; ++b) {
+            if (pos + b < kSlot - kHdr) {
+                body[pos + b] = static_cast<uint8_t>(word >> (24u - 8u * b));
+            } else {
+                overflow = true;
+            }
+        }
+        return pos + tail_bytes;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Encoder state of one packet (arCompress :487-531).
+// ---------------------------------------------------------------------------
+template <uint32_t kStride>
+struct EncoderLane {
+    ModelTree<kStride> model;
+    BitSink sink;
+    uint32_t lo, hi, pending;
+
+    GPUAR_LANE void open(uint16_t *col, uint8_t *slot) {
+        model.col = col;
+        model.reset();
+        sink.open(slot + kHdr);
+        lo = 0;             // :492-494
+        hi = 0xFFFFu;
+        pending = 0;
+    }
+
+    // symbol number i of the packet (model total = 256 + i), rc = reciprocal of that total
+    GPUAR_LANE void step(uint32_t x, uint32_t i, Recip rc) {
+        const uint32_t cums = model.encode_step(x, 256u + i);
+        narrow(lo, hi, cums & 0xFFFFu, cums >> 16, rc);
+        const uint32_t hi_before = hi;
+        const Renorm r = renorm_split(lo, hi);
+        if (r.e) {
+            // agreed MSB b, then `pending` copies of !b, then the other e-1 agreed bits
+            const uint32_t agreed = hi_before >> (16u - r.e);
+            const uint32_t b_top = agreed >> (r.e - 1u);
+            const uint32_t rest = agreed & ((1u << (r.e - 1u)) - 1u);
+            if (pending <= 16u) {
+                const uint32_t run = b_top ? (1u << pending) : ((1u << pending) - 1u);
+                sink.put((run << (r.e - 1u)) | rest, r.e + pending);
+            } else {
+                sink.put(b_top, 1u);
+                sink.put_run(b_top ^ 1u, pending);
+                if (r.e > 1u) sink.put(rest, r.e - 1u);
+            }
+            pending = 0;
+        }
+        pending += r.u;
+    }
+
+    // flush (writeRemaining :379-388, writeClose :430-439) and write the
+    // packet header (:525-528); returns clen, sets `overflowed` when the
+    // packet did not fit its slot (its stored length is then clamped).
+    GPUAR_LANE uint32_t finish(uint8_t *slot, uint32_t ulen, bool &overflowed) {
+        const uint32_t b = (lo >> 14) & 1u;
+        sink.put(b, 1u);
+        sink.put_run(b ^ 1u, pending + 1u);
+        uint32_t clen = sink.close() + kHdr;
+        overflowed = sink.overflow || clen > kSlot;
+        if (overflowed) clen = kSlot;
+        const uint32_t hdr = clen | (ulen << 16);   // u16 LE clen, u16 LE ulen
+        memcpy(slot, &hdr, 4);
+        return clen;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Bit source for the decoder (readBit/getChar :533-569).  Aligned dwords are
+// fetched one ahead; reads never leave [.., limit).
+// ---------------------------------------------------------------------------
+struct BitSource {
+    uint64_t win;        // next bits, left-aligned
+    uint32_t n;          // valid bits in win
+    uint32_t ahead;      // next dword, already byte-swapped
+    const uint8_t *next; // address of the dword after `ahead` (4-byte aligned)
+    const uint8_t *limit;
+
+    GPUAR_LANE uint32_t fetch() {
+        uint32_t w = 0;
+        if (next + 4 <= limit) {
+            memcpy(&w, next, 4);
+            w = bswap32(w);
+        } else {
+            for (int b = 0; b < 4; ++b)
+                if (next + b < limit) w |= static_cast<uint32_t>(next[b]) << (24 - 8 * b);
+        }
+        next += 4;
+        return w;
+    }
+    GPUAR_LANE void refill() {
+        if (n <= 32u) {
+            win |= static_cast<uint64_t>(ahead) << (32u - n);
+            n += 32u;
+            ahead = fetch();
+        }
+    }
+    GPUAR_LANE uint32_t take(uint32_t count) {  // count <= 31, n >= count
+        const uint32_t v = static_cast<uint32_t>((win >> 1) >> (63u - count));
+        win <<= count;
+        n -= count;
+        return v;
+    }
+    // `body` may sit at any byte address: fetch aligned dwords from the one
+    // containing it and drop the leading bytes (the packet's own header, or
+    // the tail of the previous packet in the same allocation).
+    GPUAR_LANE void open(const uint8_t *body, const uint8_t *lim) {
+        const uint32_t skip = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(body) & 3u);
+        next = body - skip;
+        limit = lim;
+        win = static_cast<uint64_t>(fetch()) << 32;
+        n = 32;
+        ahead = fetch();
+        if (skip) {
+            take(8u * skip);
+            refill();
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Decoder state of one packet (arDecompress :848-892).
+// ---------------------------------------------------------------------------
+template <uint32_t kStride>
+struct DecoderLane {
+    ModelTree<kStride> model;
+    BitSource bits;
+    uint32_t lo, hi, code;
+    uint32_t ulen;       // symbols this lane still has to produce in total
+    uint32_t outword;
+    bool bad;
+
+    // pkt -> 4-byte packet header; bytes in [pkt, limit) are readable.  A lane
+    // without a packet passes live = false and does nothing afterwards.
+    GPUAR_LANE void open(uint16_t *col, const uint8_t *pkt, const uint8_t *limit, bool live) {
+        model.col = col;
+        model.reset();
+        ulen = 0;
+        bad = false;
+        outword = 0;
+        if (live) {
+            const uint32_t clen = pkt[0] | (static_cast<uint32_t>(pkt[1]) << 8);
+            ulen = pkt[2] | (static_cast<uint32_t>(pkt[3]) << 8);
+            if (ulen > kPacket || clen < kHdr) {   // the reference would run off its buffers here
+                bad = true;
+                ulen = 0;
+            }
+        }
+        bits.open(live ? pkt + kHdr : pkt, live ? limit : pkt);
+        lo = 0;
+        hi = 0xFFFFu;
+        code = bits.take(16);   // initializeDecoder :582-603
+    }
+
+    // produce symbol i (call only while i < ulen); `out` is the packet's
+    // 4-byte-aligned output base
+    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
+        const uint32_t total = 256u + i;
+        bits.refill();
+        // getUnscaledCode :703-716 -- the divisor (range) differs per lane:
+        // reciprocal estimate, then an exact integer correction (the estimate is
+        // within 1 of the quotient: q < 2^14, relative error < 2^-21)
+        const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
+        const uint32_t num = (((code - lo) & 0xFFFFu) + 1u) * total - 1u;
+        uint32_t q = GPUAR_RCP_QUOT(num, range);
+        int32_t rem = static_cast<int32_t>(num - q * range);
+        if (rem < 0) {
+            --q;
+            rem += static_cast<int32_t>(range);
+        }
+        if (rem >= static_cast<int32_t>(range)) ++q;
+        if (q >= total) {        // no symbol owns this code value (:873-877): stop this lane
+            bad = true;
+            ulen = i;
+            return;
+        }
+        uint32_t cum_lo, cum_hi;
+        const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
+        outword |= sym << (8u * (i & 3u));
+        if ((i & 3u) == 3u) {
+            memcpy(out + (i & ~3u), &outword, 4);
+            outword = 0;
+        }
+        narrow(lo, hi, cum_lo, cum_hi, rc);
+        const Renorm r = renorm_split(lo, hi);
+        // e agree-shifts pull e bits into code; every underflow shift is
+        // `code ^= 0x4000` then a shift, i.e. bit 14 dropped and the MSB kept
+        code = ((code << r.e) | bits.take(r.e)) & 0xFFFFu;
+        if (r.u) code = (((code << r.u) ^ 0x8000u) | bits.take(r.u)) & 0xFFFFu;
+    }
+
+    // bytes of a packet whose length is not a multiple of 4
+    GPUAR_LANE void finish(uint8_t *out) {
+        for (uint32_t b = ulen & ~3u; b < ulen; ++b) out[b] = static_cast<uint8_t>(outword >> (8u * (b & 3u)));
+    }
+};
+
+}  // namespace gpuar
+#endif  // GPUAR_LANE_CODEC_H

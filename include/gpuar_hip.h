@@ -1,0 +1,130 @@
+/*
+ * gpuar_hip.h -- C ABI of the MI355X-native (gfx950) arithmetic-coding path.
+ *
+ * This is the drop-in boundary for the GPU encode/decode path of
+ * jiahansu/GPUAR.  The first three entry points carry the reference's own
+ * names and signatures, so the reference's GPUCompressor
+ * (src/gpu_compressor.cpp:19,185,357) links against libgpuar_hip.so unchanged;
+ * the gpuar_hip_* entry points are the stream- and device-explicit native ABI
+ * the rest of this repository (C++ host classes, Python bindings, bench) uses.
+ *
+ * Plain pointers and sizes only.  All `d_*` / `source` / `destination`
+ * pointers are DEVICE pointers owned by the caller (hipMalloc, or any
+ * allocator that yields HIP device memory, e.g. a torch CUDA tensor).
+ * Nothing here allocates device memory except the explicit workspace calls,
+ * and nothing throws across the boundary.
+ *
+ * Packet geometry (reference: src/gpu.h:8-14):
+ *   input  is cut into 8192-byte packets, packet p = bytes [p*8192, ...)
+ *   output packet p lives in the 8704-byte slot at p*8704; only its first
+ *          `clen` bytes are defined: u16 LE clen (incl. this 4-byte header),
+ *          u16 LE ulen, then the MSB-first arithmetic-coded bitstream
+ *          (src/gpuar_kernel.cu:523-528).
+ */
+#ifndef GPUAR_HIP_H
+#define GPUAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPUAR_PACKET_BYTES        8192u  /* UNCOMPRESSED_PACKET_SIZE, src/gpu.h:13 */
+#define GPUAR_SLOT_BYTES          8704u  /* COMPRESSED_PACKET_SIZE,   src/gpu.h:12 */
+#define GPUAR_PACKET_HEADER_BYTES 4u     /* PACKET_HEADER_LENGTH,     src/gpu.h:14 */
+
+/* Error codes returned by the gpuar_hip_* calls (0 = ok).  Positive values
+ * are hipError_t codes passed through unchanged. */
+#define GPUAR_OK                 0
+#define GPUAR_ERR_ALIGNMENT     (-1)  /* device pointer not 16-byte aligned            */
+#define GPUAR_ERR_ARGUMENT      (-2)  /* null pointer / size out of range              */
+#define GPUAR_ERR_NO_DEVICE     (-3)  /* no HIP device visible                         */
+
+/* Bits of the device status word (gpuar_hip_status). */
+#define GPUAR_STATUS_SLOT_OVERFLOW  0x1u /* a packet outgrew its 8704-byte slot; its slot is truncated
+                                            (the reference would write past the slot, SURVEY.md s.7 risk 3) */
+#define GPUAR_STATUS_BAD_PACKET     0x2u /* decode met a malformed packet (ulen > 8192, clen < 4, or a code
+                                            value outside the model, src/gpuar_kernel.cu:873-877)          */
+
+/* ------------------------------------------------------------------------
+ * Reference-named entry points (the reference's kernel object exports these;
+ * declarations: /root/reference/src/gpuar.h:74,77,78).
+ * ---------------------------------------------------------------------- */
+
+/* Replaces initConstantRange (src/gpuar_kernel.cu:453-460), which uploads the
+ * initial uniform model to __constant__ memory.  The HIP kernels build the
+ * initial model in LDS themselves and read their reciprocal table from a
+ * compile-time constant, so this only selects/initialises the current device
+ * context; calling it is optional and idempotent. */
+void initConstantRange(void);
+
+/* Replaces garCompressExecutor (src/gpuar_kernel.cu:936-944): encodes the
+ * `size` bytes at `source` into ceil(size/8192) slots at `destination`.
+ * Asynchronous on the NULL stream, like the reference's <<<>>> launch; errors
+ * surface at the caller's next synchronising HIP call and through
+ * gpuar_hip_last_error().  `numBlocks` (the reference's grid size for
+ * 32-thread blocks) is accepted and ignored: the launch shape is derived
+ * from `size`. */
+void garCompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks);
+
+/* Replaces garDecompressExecutor (src/gpuar_kernel.cu:946-954): `size` is
+ * numPackets*8704 (src/gpu_compressor.cpp:357); slot p decodes to
+ * destination + p*8192. */
+void garDecompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks);
+
+/* ------------------------------------------------------------------------
+ * Native ABI: explicit stream (a hipStream_t passed as void*; NULL = the
+ * NULL stream), int return codes, usable from one host thread per GPU.
+ * ---------------------------------------------------------------------- */
+
+/* Number of packets / slots for an input of n_bytes. */
+size_t gpuar_hip_packet_count(size_t n_bytes);
+
+/* Encode n_bytes at d_in (16-byte aligned) into packet slots at d_slots
+ * (16-byte aligned, gpuar_hip_packet_count(n_bytes)*8704 bytes). */
+int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void *stream);
+
+/* Decode n_packets slots at d_slots into d_out (n_packets*8192 bytes; the
+ * last packet writes only its ulen bytes). */
+int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, void *stream);
+
+/* Device-side compaction (what the reference does with one 8704-byte D2H copy
+ * and one fwrite per packet, src/gpu_compressor.cpp:138,161-168):
+ *   d_offsets[p]   = sum of clen of packets < p   (n_packets+1 entries, u64)
+ *   d_stream       = packets back to back, exactly the bytes that follow the
+ *                    20-byte header in a .gip file.
+ * d_stream needs room for the sum of clen (<= n_packets*8704). */
+int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_stream,
+                      uint64_t *d_offsets, void *stream);
+
+/* Decode straight from a back-to-back packet stream: d_offsets[p] is the byte
+ * offset of packet p in d_stream (n_packets+1 entries; the host builds it by
+ * walking `off += clen`, src/gpu_compressor.cpp:299-312, or keeps the array
+ * gpuar_hip_compact produced). */
+int gpuar_hip_decode_stream(const uint8_t *d_stream, const uint64_t *d_offsets, size_t n_packets,
+                            uint8_t *d_out, void *stream);
+
+/* Reads and clears the device status word of the current device
+ * (synchronises the device). */
+int gpuar_hip_status(uint32_t *flags);
+
+/* Last error recorded by a void-returning reference-named entry point on this
+ * host thread (0 = none); cleared by the call. */
+int gpuar_hip_last_error(void);
+
+const char *gpuar_hip_error_string(int code);
+
+/* Build identification, e.g. "gpuar-hip 0.1 gfx950". */
+const char *gpuar_hip_version(void);
+
+/* Synthetic streams of SURVEY.md section 8(d), generated on the device so
+ * multi-GiB benchmark inputs never cross PCIe.  kind: 0 uniform, 1 zipf,
+ * 2 text.  Fills d_out[0..n) with bytes [offset, offset+n) of the stream. */
+int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8_t *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUAR_HIP_H */

@@ -1,0 +1,76 @@
+// tests/lane_emulation.cpp -- TEST HARNESS (CPU).  Runs the per-lane codec of
+// gpuar_amd/csrc/lane_codec.h (the code the gfx950 kernels execute per lane)
+// one packet at a time on the host, so its closed forms can be compared with
+// the oracle in a container without a GPU.  Built by tests/test_lane_emulation.py
+// into tests/_build/liblane_emulation.so; never linked into a product library.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "../gpuar_amd/csrc/lane_codec.h"
+
+using namespace gpuar;
+
+static const RecipTable kRecip = RecipTable();
+
+extern "C" {
+
+// slots: ceil(n/8192) * 8704 bytes.  Returns the OR of per-packet overflow flags.
+int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+{
+    int any_overflow = 0;
+    const size_t np = (n_bytes + kPacket - 1) / kPacket;
+    std::vector<uint16_t> tree(kTreeRows);
+    for (size_t p = 0; p < np; ++p) {
+        const size_t off = p * kPacket;
+        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
+        uint8_t *slot = slots + p * kSlot;
+        EncoderLane<1> enc;
+        enc.open(tree.data(), slot);
+        for (uint32_t i = 0; i < len; ++i) enc.step(in[off + i], i, kRecip.r[i]);
+        bool ov;
+        enc.finish(slot, len, ov);
+        any_overflow |= ov ? 1 : 0;
+    }
+    return any_overflow;
+}
+
+// pkt_offsets: np+1 byte offsets into `stream`; out: np * 8192 bytes.
+// Returns the number of packets flagged bad.
+int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)
+{
+    int bad = 0;
+    std::vector<uint16_t> tree(kTreeRows);
+    const uint8_t *limit = stream + pkt_offsets[np];
+    for (size_t p = 0; p < np; ++p) {
+        DecoderLane<1> dec;
+        uint8_t *o = out + p * kPacket;
+        dec.open(tree.data(), stream + pkt_offsets[p], limit, true);
+        for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
+        dec.finish(o);
+        bad += dec.bad ? 1 : 0;
+    }
+    return bad;
+}
+
+// Check of the reciprocal table: for every total d, the multiple boundaries
+// k*d-1 and k*d (stepping k by `stride`) plus the largest numerator
+// d*65536-1.  Returns the number of mismatches.
+uint64_t emu_check_recip(uint32_t stride)
+{
+    uint64_t wrong = 0;
+    for (uint32_t i = 0; i < kPacket; ++i) {
+        const uint32_t d = 256u + i;
+        const uint32_t top = d * 65536u - 1u;
+        for (uint64_t k = 1; k * d <= top; k += stride) {
+            const uint32_t a = static_cast<uint32_t>(k * d), b = a - 1u;
+            wrong += div_total(a, kRecip.r[i]) != a / d;
+            wrong += div_total(b, kRecip.r[i]) != b / d;
+        }
+        wrong += div_total(top, kRecip.r[i]) != top / d;
+        wrong += div_total(0, kRecip.r[i]) != 0;
+    }
+    return wrong;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol
+include/gpuar_hip.h declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from gpuar_amd import hip as H
+    if not os.path.exists(H.LIB_PATH):
+        g.build()
+    return H.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpuar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+    return sorted(set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    from gpuar_amd import hip as H
+    names = declared_symbols()
+    assert set(names) == set(H.EXPORTS), (names, H.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_only_calls(lib):
+    assert lib.gpuar_hip_packet_count(0) == 0
+    assert lib.gpuar_hip_packet_count(1) == 1
+    assert lib.gpuar_hip_packet_count(8192) == 1
+    assert lib.gpuar_hip_packet_count(8193) == 2
+    assert b"gfx950" in lib.gpuar_hip_version()
+    assert lib.gpuar_hip_error_string(0) == b"ok"
+    assert b"align" in lib.gpuar_hip_error_string(-1)
+    assert lib.gpuar_hip_last_error() == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gpuar_amd import hip as H
+    monkeypatch.setattr(H, "_lib", None)
+    monkeypatch.setattr(H, "LIB_PATH", "/nonexistent/libgpuar_hip.so")
+    with pytest.raises(H.GpuarError):
+        H.load()
+
+
+def test_header_layout_helper():
+    from gpuar_amd import hip as H
+    h = H.gip_header(65539, 66067)
+    assert len(h) == 20 and h[0:3] == b"\x00\x01\x00"
+    assert int.from_bytes(h[4:8], "little") == 65539
+    assert int.from_bytes(h[12:16], "little") == 66087

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP kernels, called through the C ABI, against the oracle.
+
+Bit-exact is the bar (integer/byte work): packet slots, compacted packet
+stream, per-packet lengths, decoded bytes.  Run on the GPU box with
+`python -m pytest tests -m gpu`.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpuar_amd import synth
+from test_oracle_golden import REFV, SURVEY, case_input, md5
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpuar_amd import hip
+    hip.load()          # raises if the HIP library is missing: no fallback
+    return hip
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O.best()
+
+
+def gpu_stream(H, data: np.ndarray):
+    """encode + compact on the GPU; returns (stream bytes, offsets, slots tensor, npk)."""
+    npk = H.packet_count(data.size)
+    if data.size == 0:
+        return np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64), None, 0
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    d_slots = H.encode(d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    torch.cuda.synchronize()
+    offs = d_off.cpu().numpy()
+    return d_stream[:int(offs[-1])].cpu().numpy(), offs, d_slots, npk
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_encode_matches_reference_fixture(H, c):
+    data = case_input(c)
+    stream, offs, d_slots, npk = gpu_stream(H, data)
+    assert H.status() == 0
+    assert stream.size == c["stream_len"]
+    assert md5(stream.tobytes()) == c["stream_md5"]
+    assert list(np.diff(offs)) == c["clens"]
+    keep = os.path.join(os.path.dirname(__file__), "golden", c["name"] + ".stream.bin")
+    if os.path.exists(keep):
+        assert stream.tobytes() == open(keep, "rb").read()
+    back = H.decode(d_slots, npk)[:data.size].cpu().numpy()
+    assert np.array_equal(back, data)
+    assert H.status() == 0
+
+
+@pytest.mark.parametrize("s", SURVEY["streams"], ids=lambda s: f"{s['kind']}-{s['seed']}-{s['n']}")
+def test_encode_matches_reference_cli_streams(H, s):
+    """BASELINE.json configs[1]: 64 MiB stand-in for data/random_64m.dat on one GPU,
+    packet stream byte-equal (md5) to the reference's --host output; plus the small cases."""
+    n = s["n"]
+    d_in = H.generate(s["kind"], s["seed"], n)
+    if n <= (1 << 20):
+        assert md5(d_in.cpu().numpy().tobytes()) == s["input_md5"]
+    npk = H.packet_count(n)
+    d_slots = H.encode(d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    total = int(d_off[-1].item())
+    assert total + 20 == s["gip_bytes"]
+    assert md5(d_stream[:total].cpu().numpy().tobytes()) == s["stream_md5"]
+    d_back = H.decode_stream(d_stream, d_off, npk)
+    assert torch.equal(d_back[:n], d_in)
+    assert H.status() == 0
+
+
+def test_device_generators_match_numpy(H):
+    for kind in synth.KINDS:
+        for off, n in [(0, 1), (0, 100003), (8192 * 3, 70001), (8, 4096)]:
+            got = H.generate(kind, 9, n, offset=off).cpu().numpy()
+            assert np.array_equal(got, synth.generate(kind, 9, n, offset=off)), (kind, off, n)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "text", "zeros"])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 8191, 8192, 8193, 64 * 8192, 64 * 8192 + 1, 200 * 8192 + 4097])
+def test_slots_equal_oracle(H, oracle_port, kind, n):
+    data = synth.generate(kind, 21, n)
+    want_slots, total = oracle_port.encode_slots(data)
+    d_slots = H.encode(torch.from_numpy(data).cuda())
+    got = d_slots.cpu().numpy()
+    npk = H.packet_count(n)
+    for p in range(npk):
+        clen = int(want_slots[p * 8704]) | (int(want_slots[p * 8704 + 1]) << 8)
+        assert np.array_equal(got[p * 8704:p * 8704 + clen], want_slots[p * 8704:p * 8704 + clen]), (kind, n, p)
+    back = H.decode(d_slots, npk)[:n].cpu().numpy()
+    assert np.array_equal(back, data)
+    assert H.status() == 0
+
+
+@pytest.fixture(scope="module")
+def oracle_port():
+    from oracle import oracle as O
+    return O.PortOracle()
+
+
+def test_reference_named_executors(H):
+    """garCompressExecutor / garDecompressExecutor / initConstantRange: same names,
+    argument meaning and NULL-stream behaviour as src/gpuar.h:74,77,78."""
+    lib = H.load()
+    n = 5 * 8192 + 99
+    data = synth.zipf(3, n)
+    d_in = torch.from_numpy(data).cuda()
+    npk = H.packet_count(n)
+    d_slots = torch.zeros(npk * 8704, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(npk * 8192, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    lib.initConstantRange()
+    lib.garCompressExecutor(d_in.data_ptr(), n, d_slots.data_ptr(), (npk + 31) // 32)
+    lib.garDecompressExecutor(d_slots.data_ptr(), npk * 8704, d_out.data_ptr(), (npk + 31) // 32)
+    torch.cuda.synchronize()
+    assert lib.gpuar_hip_last_error() == 0
+    assert np.array_equal(d_out[:n].cpu().numpy(), data)
+    from oracle import oracle as O
+    want, _ = O.PortOracle().encode_slots(data)
+    got = d_slots.cpu().numpy()
+    for p in range(npk):
+        clen = int(want[p * 8704]) | (int(want[p * 8704 + 1]) << 8)
+        assert np.array_equal(got[p * 8704:p * 8704 + clen], want[p * 8704:p * 8704 + clen])
+
+
+def test_argument_errors(H):
+    lib = H.load()
+    buf = torch.zeros(8704 * 2 + 64, dtype=torch.uint8, device="cuda")
+    assert lib.gpuar_hip_encode(buf.data_ptr() + 1, 100, buf.data_ptr(), None) == -1      # misaligned input
+    assert lib.gpuar_hip_encode(None, 100, buf.data_ptr(), None) == -2
+    assert lib.gpuar_hip_encode(buf.data_ptr(), 0, buf.data_ptr(), None) == 0              # empty input: nothing to do
+    lib.garCompressExecutor(buf.data_ptr() + 1, 100, buf.data_ptr(), 1)
+    assert lib.gpuar_hip_last_error() == -1 and lib.gpuar_hip_last_error() == 0
+
+
+def test_malformed_packets_are_flagged_not_fatal(H):
+    rng = np.random.default_rng(5)
+    npk = 64
+    slots = rng.integers(0, 256, npk * 8704, dtype=np.uint8)
+    for p in range(npk):
+        slots[p * 8704:p * 8704 + 2] = np.frombuffer(int(8000).to_bytes(2, "little"), dtype=np.uint8)
+        ulen = 8192 if p % 2 else 60000          # half the packets claim an impossible length
+        slots[p * 8704 + 2:p * 8704 + 4] = np.frombuffer(int(ulen).to_bytes(2, "little"), dtype=np.uint8)
+    d_out = torch.full((npk * 8192 + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+    H.decode(torch.from_numpy(slots).cuda(), npk, d_out)
+    flags = H.status()
+    assert flags & H.STATUS_BAD_PACKET
+    assert bool((d_out[npk * 8192:] == 0xA5).all())
+    assert H.status() == 0                        # status is read-and-clear
+
+
+def test_round_trip_properties_at_scale(H):
+    """1 GiB text (BASELINE.json configs[2]) on one GPU: size-independent checks --
+    decode(encode(x)) == x, slot lengths sum to the compacted size, compaction is
+    a pure gather (stream decodes to the same bytes), ratio in the expected band."""
+    n = 1 << 30
+    d_in = H.generate("text", 1, n)
+    npk = H.packet_count(n)
+    d_slots = H.encode(d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    total = int(d_off[-1].item())
+    clen = d_slots.view(npk, 8704)[:, 0].to(torch.int64) | (d_slots.view(npk, 8704)[:, 1].to(torch.int64) << 8)
+    assert int(clen.sum().item()) == total
+    assert torch.equal(torch.cumsum(clen, 0), d_off[1:])
+    assert 0.66 < total / n < 0.69            # measured ratio 0.675 for text
+    d_back = H.decode(d_slots, npk)
+    assert torch.equal(d_back[:n], d_in)
+    del d_back
+    d_back2 = H.decode_stream(d_stream, d_off, npk)
+    assert torch.equal(d_back2[:n], d_in)
+    assert H.status() == 0
+    # oracle spot check: 32 packets from the middle
+    from oracle import oracle as O
+    p0 = npk // 2
+    host = d_in[p0 * 8192:(p0 + 32) * 8192].cpu().numpy()
+    want = O.best().encode_stream(host)
+    got = d_stream[int(d_off[p0].item()):int(d_off[p0 + 32].item())].cpu().numpy()
+    assert np.array_equal(got, want)
