@@ -64,49 +64,110 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) 
 
 // ---------------------------------------------------------------------------
 // Encode: replaces garCompress + arCompress (src/gpuar_kernel.cu:894-914, 487-531)
+//
+// Workgroup = 2 wavefronts serving the same 64 packets (lane l <-> packet
+// 64*block + l in both):
+//   wave 0, the MODELER, owns the 64 adaptive models (32 KiB of LDS), reads
+//           the input bytes and turns each symbol into cumLo | cumHi << 16;
+//   wave 1, the CODER, owns the interval state and the bit sink, and turns
+//           those words into the packet bitstream.
+// They meet in a two-half LDS ring of kPhase symbols per half: the modeler
+// fills half (k & 1) while the coder drains the other, one s_barrier per
+// phase.  Why: a packet's model pins 512 B of LDS, so a CU can hold at most
+// 4-5 x 64 packets; splitting the per-symbol work over two wavefronts puts two
+// wavefronts on every SIMD for the same LDS, which is what this
+// latency-/issue-bound integer chain needs.  40 KiB of LDS per workgroup ->
+// exactly 4 workgroups (8 wavefronts) per CU.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kLanes)
-encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
-    __shared__ uint16_t tree[kTreeRows * kLanes];  // 32 KiB: 255 nodes x 64 lanes x u16
+constexpr uint32_t kPhase = 16;
 
-    const uint32_t lane = threadIdx.x;
+struct EncodeLds {
+    uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
+    uint32_t ring[2][kPhase][kLanes];          // 8 KiB: cumLo | cumHi << 16
+};
+
+// LDS only: the global loads/stores of either wave stay in flight across the barrier
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ void __launch_bounds__(2 * kLanes)
+encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
+    __shared__ EncodeLds lds;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const size_t start = packet * kPacket;
     const uint32_t len = live ? static_cast<uint32_t>(size - start < kPacket ? size - start : kPacket) : 0u;
-    const uint8_t *in = src + (live ? start : 0);
-    uint8_t *slot = dst + (live ? packet : 0) * static_cast<size_t>(kSlot);
-
-    EncoderLane<kLanes> enc;
-    enc.open(tree + lane_column(lane), slot);
-
-    // wave-uniform trip count: every lane but (possibly) the file's last packet has 8192 symbols
     const uint32_t len_max = wave_max(len);
+    const uint32_t len_min = wave_max(~len) ^ 0xFFFFFFFFu;
+    const uint32_t n_phases = (len_max + kPhase - 1) / kPhase;
 
-    uint4 chunk = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
-    for (uint32_t base = 0; base < len_max; base += 16) {
-        const uint4 cur = chunk;
-        if (base + 16 < len) chunk = load16_guarded(in + base + 16, len - (base + 16));
-        const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+    if (role == 0) {
+        // ------------------------------ modeler ------------------------------
+        const uint8_t *in = src + (live ? start : 0);
+        InorderModel<7> model;
+        model.col = lds.tree + 2u * lane_column(lane);
+        model.reset();
+        uint4 chunk = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
+        for (uint32_t k = 0; k <= n_phases; ++k) {
+            if (k < n_phases) {
+                const uint32_t base = k * kPhase;
+                const uint4 cur = chunk;
+                if (base + kPhase < len) chunk = load16_guarded(in + base + kPhase, len - (base + kPhase));
+                uint32_t(*out)[kLanes] = lds.ring[k & 1u];
+                const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+                if (base + kPhase <= len_min) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t word = words[q];
+                    for (uint32_t j = 0; j < kPhase; ++j) {
+                        const uint32_t x = (words[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+                        out[j][lane] = model.step(x, 256u + base + j);
+                    }
+                } else {                       // the phase that holds the file's ragged tail
 #pragma unroll 1
-            for (uint32_t b = 0; b < 4; ++b) {
-                const uint32_t i = base + 4u * q + b;        // wave-uniform symbol index
-                if (i >= len_max) break;
-                const Recip rc = g_recip.r[i];               // scalar load: total = 256 + i
-                const uint32_t x = word & 0xFFu;
-                word >>= 8;
-                if (i < len) enc.step(x, i, rc);
+                    for (uint32_t j = 0; j < kPhase; ++j) {
+                        const uint32_t w = j < 4 ? cur.x : j < 8 ? cur.y : j < 12 ? cur.z : cur.w;
+                        const uint32_t x = (w >> (8u * (j & 3u))) & 0xFFu;
+                        if (base + j < len) out[j][lane] = model.step(x, 256u + base + j);
+                    }
+                }
             }
+            lds_barrier();
         }
-    }
-
-    if (live) {
-        bool overflowed;
-        enc.finish(slot, len, overflowed);
-        if (overflowed) atomicOr(&g_status, GPUAR_STATUS_SLOT_OVERFLOW);
+    } else {
+        // ------------------------------- coder -------------------------------
+        uint8_t *slot = dst + (live ? packet : 0) * static_cast<size_t>(kSlot);
+        CoderLane coder;
+        coder.open(slot);
+        for (uint32_t k = 0; k <= n_phases; ++k) {
+            if (k >= 1) {
+                const uint32_t base = (k - 1u) * kPhase;
+                const uint32_t(*in)[kLanes] = lds.ring[(k - 1u) & 1u];
+                const Recip *rc = &g_recip.r[base];          // wave-uniform: scalar loads
+                if (base + kPhase <= len_min) {
+                    uint32_t cums[kPhase];
+#pragma unroll
+                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in[j][lane];
+#pragma unroll
+                    for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
+                } else {
+#pragma unroll 1
+                    for (uint32_t j = 0; j < kPhase; ++j) {
+                        if (base + j >= len_max) break;
+                        const Recip r = rc[j];
+                        if (base + j < len) coder.step(in[j][lane], r);
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        if (live) {
+            bool overflowed;
+            coder.finish(slot, len, overflowed);
+            if (overflowed) atomicOr(&g_status, GPUAR_STATUS_SLOT_OVERFLOW);
+        }
     }
 }
 
@@ -166,22 +227,23 @@ __device__ __forceinline__ uint32_t slot_clen(const uint8_t *slots, size_t p) {
     return *reinterpret_cast<const uint16_t *>(slots + p * kSlot);
 }
 
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &block_total) {
-    __shared__ uint32_t wave_sums[kScanThreads / kLanes];
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T &block_total) {
+    __shared__ T wave_sums[kScanThreads / kLanes];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
+    T incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t other = __shfl_up(incl, off);
+        const T other = __shfl_up(incl, off);
         if (lane >= static_cast<uint32_t>(off)) incl += other;
     }
     if (lane == 63u) wave_sums[wave] = incl;
     __syncthreads();
-    uint32_t before = 0, total = 0;
+    T before = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kScanThreads / kLanes; ++w) {
-        const uint32_t s = wave_sums[w];
-        before += (w < wave) ? s : 0u;
+        const T s = wave_sums[w];
+        before += (w < wave) ? s : T(0);
         total += s;
     }
     __syncthreads();
@@ -208,9 +270,9 @@ scan_tile_prefix_kernel(uint32_t n_tiles) {   // one block; n_tiles <= 4096
     for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
         const uint32_t t = base + threadIdx.x;
         const uint64_t v = t < n_tiles ? g_tile_prefix[t] : 0;
-        // tile sums fit 32 bits (4096 * 8704), prefixes need 64
-        uint32_t total;
-        const uint32_t excl = block_exclusive_scan(static_cast<uint32_t>(v), total);
+        // a tile sum fits 32 bits (4096 * 8704); sums over tiles need 64
+        uint64_t total;
+        const uint64_t excl = block_exclusive_scan<uint64_t>(v, total);
         const uint64_t start = carry;
         if (t < n_tiles) g_tile_prefix[t] = start + excl;
         __syncthreads();
@@ -356,7 +418,7 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
-    gpuar::encode_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+    gpuar::encode_kernel<<<blocks, 2 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
     return check_launch();
 }

@@ -279,6 +279,118 @@ struct EncoderLane {
     }
 };
 
+// ===========================================================================
+// Split encoder: the model walk and the range coder as two separate lane
+// programs, joined by one 32-bit word per symbol (cumLo | cumHi << 16).  On the
+// GPU they run in two different wavefronts of a workgroup (a "modeler" and a
+// "coder" wave serving the same 64 packets through an LDS ring), so that every
+// SIMD holds two wavefronts although a packet's model pins 32 KiB of LDS per
+// 64 packets.  Same arithmetic as EncoderLane above, re-expressed to cost
+// fewer vector instructions.
+// ===========================================================================
+
+// Model tree in IN-ORDER layout: the node at depth k on the path of symbol x
+// sits in row (x & topmask_k) | ((1 << (7-k)) - 1), so its address is one
+// AND-OR of the pre-shifted symbol plus a compile-time offset.  kRowShift =
+// log2(bytes between rows): 7 on the GPU (64 lanes x u16), 1 on the host.
+template <uint32_t kRowShift>
+struct InorderModel {
+    uint8_t *col;   // this lane's column: row r lives at col + (r << kRowShift)
+
+    GPUAR_LANE uint16_t *node(uint32_t x_shifted, int k) const {
+        const uint32_t keep = ((0xFF00u >> k) & 0xFFu) << kRowShift;     // top k bits of the symbol
+        const uint32_t fixed = ((1u << (7 - k)) - 1u) << kRowShift;
+        return reinterpret_cast<uint16_t *>(col + ((x_shifted & keep) | fixed));
+    }
+
+    GPUAR_LANE void reset() {
+#pragma unroll 1
+        for (uint32_t row = 0; row < 255u; ++row) {
+            // row r is a node of depth 7 - (number of trailing ones of r)
+            const uint32_t trailing_ones = 31u - GPUAR_CLZ32((row ^ (row + 1u)));
+            *reinterpret_cast<uint16_t *>(col + (row << kRowShift)) = static_cast<uint16_t>(1u << trailing_ones);
+        }
+    }
+
+    // returns cumLo | cumHi << 16 for symbol x (model total = `total`) and counts x
+    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total) {
+        const uint32_t xs = x << kRowShift;
+        // bit j of the low half = bit j of x, of the high half = bit j of x + 1
+        const uint32_t z = x * 0x10001u + 0x10000u;
+        uint32_t left[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) left[k] = *node(xs, k);
+        uint32_t acc = ((z >> 8) & 0x10001u) * total;       // x == 255: cumHi is the whole total
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t pick = (z >> (7 - k)) & 0x10001u;  // low: path goes right at depth k; high: same for x+1
+            acc += left[k] * pick;
+            *node(xs, k) = static_cast<uint16_t>((pick ^ 1u) + left[k]);   // +1 where x goes left
+        }
+        return acc;
+    }
+};
+
+// Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
+// State: lo and nh = 0xFFFF - hi packed as lo | nh << 16, so that both bounds
+// renormalise with the same left shift (zeros enter lo, ones enter hi).
+struct CoderLane {
+    uint32_t p;          // lo | (0xFFFF - hi) << 16
+    uint32_t pending;
+    BitSink sink;
+
+    GPUAR_LANE void open(uint8_t *slot) {
+        p = 0;            // lo = 0, hi = 0xFFFF  (:492-494)
+        pending = 0;
+        sink.open(slot + kHdr);
+    }
+
+    GPUAR_LANE void step(uint32_t cums, Recip rc) {
+        const uint32_t lo = p & 0xFFFFu;
+        const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
+        const uint32_t range = above - (p >> 16);             // hi - lo + 1
+        const uint32_t up = div_total((cums >> 16) * range, rc);
+        const uint32_t dn = div_total((cums & 0xFFFFu) * range, rc);
+        const uint32_t a = lo + dn;                           // new lo
+        const uint32_t b = above - up;                        // 0xFFFF - new hi
+        // e = agreeing MSBs of new lo / new hi = leading ones of a ^ b (16 bit)
+        const uint32_t e = GPUAR_CLZ32(~((a ^ b) << 16));
+        const uint32_t a1 = (a << e) & 0xFFFFu, b1 = (b << e) & 0xFFFFu;
+        // underflow run: from bit 14 down, lo has 1 and hi has 0  <=>  a1 & b1
+        const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
+        p = ((a1 << u) & 0x7FFFu) | (((b1 << u) & 0x7FFFu) << 16);
+        if (e) {
+            const uint32_t agreed = a >> (16u - e);           // the e agreed bits (same in lo and hi)
+            const uint32_t em1 = e - 1u;
+            const uint32_t top = agreed >> em1;
+            const uint32_t rest = agreed & ((1u << em1) - 1u);
+            if (pending <= 16u) {
+                // top, then `pending` copies of !top, then rest
+                const uint32_t fill = (1u << pending) - 1u + top;
+                sink.put((fill << em1) | rest, e + pending);
+            } else {
+                sink.put(top, 1u);
+                sink.put_run(top ^ 1u, pending);
+                if (em1) sink.put(rest, em1);
+            }
+            pending = 0;
+        }
+        pending += u;
+    }
+
+    GPUAR_LANE uint32_t finish(uint8_t *slot, uint32_t ulen, bool &overflowed) {
+        const uint32_t b = (p >> 14) & 1u;                    // bit 14 of lo
+        sink.put(b, 1u);
+        sink.put_run(b ^ 1u, pending + 1u);
+        uint32_t clen = sink.close() + kHdr;
+        overflowed = sink.overflow || clen > kSlot;
+        if (overflowed) clen = kSlot;
+        const uint32_t hdr = clen | (ulen << 16);
+        memcpy(slot, &hdr, 4);
+        return clen;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Bit source for the decoder (readBit/getChar :533-569).  Aligned dwords are
 // fetched one ahead; reads never leave [.., limit).

@@ -33,6 +33,8 @@ def emu():
     lib = C.CDLL(so)
     lib.emu_encode_slots.restype = C.c_int
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_split.restype = C.c_int
+    lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
@@ -40,11 +42,12 @@ def emu():
     return lib
 
 
-def emu_encode(lib, data: np.ndarray):
+def emu_encode(lib, data: np.ndarray, split=False):
     npk = (data.size + 8191) // 8192
     slots = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
     src = np.ascontiguousarray(data)
-    ov = lib.emu_encode_slots(src.ctypes.data_as(u8p), src.size, slots.ctypes.data_as(u8p))
+    fn = lib.emu_encode_slots_split if split else lib.emu_encode_slots
+    ov = fn(src.ctypes.data_as(u8p), src.size, slots.ctypes.data_as(u8p))
     return slots, npk, ov
 
 
@@ -68,6 +71,17 @@ def emu_decode(lib, stream, offs, npk):
 def test_reciprocal_table_is_exact(emu):
     # every total, every 97th multiple boundary on both sides, plus the extremes
     assert emu.emu_check_recip(97) == 0
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_split_encoder_matches_reference_fixture(emu, port_oracle, c):
+    """InorderModel + CoderLane: what the modeler / coder wavefronts of the encode kernel run."""
+    data = case_input(c)
+    slots, npk, ov = emu_encode(emu, data, split=True)
+    assert ov == 0
+    stream, _ = slots_to_stream(slots, npk)
+    assert stream.size == c["stream_len"]
+    assert np.array_equal(stream, port_oracle.encode_stream(data))
 
 
 @pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
@@ -97,6 +111,8 @@ def test_lane_codec_random_packets(emu, port_oracle):
         slots, npk, ov = emu_encode(emu, data)
         stream, offs = slots_to_stream(slots, npk)
         assert ov == 0 and np.array_equal(stream, port_oracle.encode_stream(data)), trial
+        slots2, _, ov2 = emu_encode(emu, data, split=True)
+        assert ov2 == 0 and np.array_equal(slots2, slots), trial
         out, bad = emu_decode(emu, stream, offs, npk)
         assert bad == 0 and np.array_equal(out[:n], data), trial
 
