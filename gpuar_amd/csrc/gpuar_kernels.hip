@@ -108,29 +108,36 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     if (role == 0) {
         // ------------------------------ modeler ------------------------------
         const uint8_t *in = src + (live ? start : 0);
-        InorderModel<7> model;
-        model.col = lds.tree + 2u * lane_column(lane);
-        model.reset();
         uint4 chunk = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
+        ModelerLane<7> model;
+        model.open(lds.tree + 2u * lane_column(lane), chunk.x & 0xFFu);
         for (uint32_t k = 0; k <= n_phases; ++k) {
             if (k < n_phases) {
                 const uint32_t base = k * kPhase;
                 const uint4 cur = chunk;
                 if (base + kPhase < len) chunk = load16_guarded(in + base + kPhase, len - (base + kPhase));
-                uint32_t(*out)[kLanes] = lds.ring[k & 1u];
-                const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+                uint32_t *out = &lds.ring[k & 1u][0][lane];
+                const uint32_t words[5] = {cur.x, cur.y, cur.z, cur.w, chunk.x};
                 if (base + kPhase <= len_min) {
 #pragma unroll
                     for (uint32_t j = 0; j < kPhase; ++j) {
                         const uint32_t x = (words[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-                        out[j][lane] = model.step(x, 256u + base + j);
+                        const uint32_t x_next = (words[(j + 1) >> 2] >> (8u * ((j + 1) & 3u))) & 0xFFu;
+                        out[j * kLanes] = model.step(x, 256u + base + j, x_next);
                     }
                 } else {                       // the phase that holds the file's ragged tail
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        uint32_t w = words[q], w_next = words[q + 1];
 #pragma unroll 1
-                    for (uint32_t j = 0; j < kPhase; ++j) {
-                        const uint32_t w = j < 4 ? cur.x : j < 8 ? cur.y : j < 12 ? cur.z : cur.w;
-                        const uint32_t x = (w >> (8u * (j & 3u))) & 0xFFu;
-                        if (base + j < len) out[j][lane] = model.step(x, 256u + base + j);
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t i = base + 4u * q + b;
+                            const uint32_t x = w & 0xFFu;
+                            w = (w >> 8) | (w_next << 24);        // next symbol now in the low byte
+                            w_next >>= 8;
+                            if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
+                            out += kLanes;
+                        }
                     }
                 }
             }
@@ -138,26 +145,41 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         }
     } else {
         // ------------------------------- coder -------------------------------
-        uint8_t *slot = dst + (live ? packet : 0) * static_cast<size_t>(kSlot);
+        // slot address = (wave-uniform base of this block's first slot) + lane * 8704
+        uint8_t *block_slots = dst + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);
         CoderLane coder;
-        coder.open(slot);
+        coder.open(block_slots, lane * kSlot);
+        constexpr uint32_t kGroup = 8;                       // reciprocals are fetched one group ahead
+        Recip rc_next[kGroup];
+#pragma unroll
+        for (uint32_t j = 0; j < kGroup; ++j) rc_next[j] = g_recip.r[j];
         for (uint32_t k = 0; k <= n_phases; ++k) {
             if (k >= 1) {
                 const uint32_t base = (k - 1u) * kPhase;
-                const uint32_t(*in)[kLanes] = lds.ring[(k - 1u) & 1u];
-                const Recip *rc = &g_recip.r[base];          // wave-uniform: scalar loads
+                const uint32_t *in = &lds.ring[(k - 1u) & 1u][0][lane];
                 if (base + kPhase <= len_min) {
                     uint32_t cums[kPhase];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in[j][lane];
+                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in[j * kLanes];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
+                    for (uint32_t g = 0; g < kPhase / kGroup; ++g) {
+                        Recip rc[kGroup];
+#pragma unroll
+                        for (uint32_t j = 0; j < kGroup; ++j) rc[j] = rc_next[j];
+                        uint32_t ahead = base + (g + 1u) * kGroup;           // wave-uniform
+                        ahead = ahead > kPacket - kGroup ? kPacket - kGroup : ahead;
+#pragma unroll
+                        for (uint32_t j = 0; j < kGroup; ++j) rc_next[j] = g_recip.r[ahead + j];
+#pragma unroll
+                        for (uint32_t j = 0; j < kGroup; ++j) coder.step(cums[g * kGroup + j], rc[j]);
+                    }
                 } else {
 #pragma unroll 1
                     for (uint32_t j = 0; j < kPhase; ++j) {
-                        if (base + j >= len_max) break;
-                        const Recip r = rc[j];
-                        if (base + j < len) coder.step(in[j][lane], r);
+                        const uint32_t i = base + j;
+                        if (i >= len_max) break;
+                        const Recip r = g_recip.r[i];
+                        if (i < len) coder.step(in[j * kLanes], r);
                     }
                 }
             }
@@ -165,7 +187,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         }
         if (live) {
             bool overflowed;
-            coder.finish(slot, len, overflowed);
+            coder.finish(len, overflowed);
             if (overflowed) atomicOr(&g_status, GPUAR_STATUS_SLOT_OVERFLOW);
         }
     }

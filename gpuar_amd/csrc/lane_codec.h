@@ -331,18 +331,116 @@ struct InorderModel {
     }
 };
 
+// The modeler as the kernel runs it: same tree, but
+//  * depths 0 and 1 (3 nodes) live in registers, depths 2..7 in LDS rows;
+//  * software-pipelined: while symbol i is being accounted, the six LDS nodes
+//    of symbol i+1 are already being fetched.  Each fetch is issued right
+//    AFTER the store to the same depth for symbol i, and LDS operations of a
+//    wavefront complete in order, so a node shared by both symbols is read
+//    with symbol i's increment already applied.
+template <uint32_t kRowShift>
+struct ModelerLane {
+    InorderModel<kRowShift> tree;
+    uint32_t root, left_half, right_half;   // depth 0, depth 1 (symbols < 128 / >= 128)
+    uint32_t left[6];                       // depths 2..7 of the NEXT symbol to account
+
+    GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
+        tree.col = col;
+        tree.reset();
+        root = 128u;
+        left_half = right_half = 64u;
+        const uint32_t xs = first_symbol << kRowShift;
+#pragma unroll
+        for (int k = 2; k < 8; ++k) left[k - 2] = *tree.node(xs, k);
+    }
+
+    // accounts symbol x (model total `total`), prefetches for x_next;
+    // returns cumLo | cumHi << 16
+    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
+        const uint32_t xs = x << kRowShift, xn = x_next << kRowShift;
+        const uint32_t z = x * 0x10001u + 0x10000u;      // low half: bits of x, high half: bits of x + 1
+        const uint32_t high = x >> 7;
+        const uint32_t quarter = x >> 6;
+        uint32_t acc = ((z >> 8) & 0x10001u) * total;      // x == 255: cumHi is the whole total
+        acc += root * ((z >> 7) & 0x10001u);
+        acc += (high ? right_half : left_half) * ((z >> 6) & 0x10001u);
+        root += high ^ 1u;
+        left_half += (quarter == 0u) ? 1u : 0u;
+        right_half += (quarter == 2u) ? 1u : 0u;
+#pragma unroll
+        for (int k = 2; k < 8; ++k) {
+            const uint32_t pick = (z >> (7 - k)) & 0x10001u;
+            const uint32_t l = left[k - 2];
+            acc += l * pick;
+            *tree.node(xs, k) = static_cast<uint16_t>((pick ^ 1u) + l);
+            left[k - 2] = *tree.node(xn, k);
+        }
+        return acc;
+    }
+};
+
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
 // State: lo and nh = 0xFFFF - hi packed as lo | nh << 16, so that both bounds
 // renormalise with the same left shift (zeros enter lo, ones enter hi).
+// Output bits gather in a 32-bit accumulator; a full dword leaves with one
+// (predicated) store.
 struct CoderLane {
     uint32_t p;          // lo | (0xFFFF - hi) << 16
-    uint32_t pending;
-    BitSink sink;
+    uint32_t pending;    // underflow bits owed
+    uint32_t acc, n;     // n (< 32) output bits, right-aligned in acc
+    uint32_t pos;        // bytes stored so far after the 4-byte packet header
+    uint8_t *base;       // same pointer in every lane of a wavefront (scalar register on the GPU) ...
+    uint32_t body_off;   // ... plus this lane's byte offset of slot + 4
 
-    GPUAR_LANE void open(uint8_t *slot) {
+    GPUAR_LANE void open(uint8_t *uniform_base, uint32_t slot_offset) {
         p = 0;            // lo = 0, hi = 0xFFFF  (:492-494)
         pending = 0;
-        sink.open(slot + kHdr);
+        acc = 0;
+        n = 0;
+        pos = 0;
+        base = uniform_base;
+        body_off = slot_offset + kHdr;
+    }
+
+    // append `count` (<= 32) bits, MSB first.  Straight-line except for the
+    // one predicated store: both outcomes are computed and selected.  A packet
+    // that outgrows its slot keeps overwriting the slot's last dword (never
+    // beyond it); finish() sees pos > limit and reports the overflow.
+    GPUAR_LANE void put(uint32_t bits, uint32_t count) {
+        const uint32_t total = n + count;                       // <= 63
+        const uint32_t left_aligned = bits << ((32u - count) & 31u);
+        // the oldest 32 bits of acc:bits (a funnel shift; n < 32)
+        const uint32_t word = static_cast<uint32_t>(((static_cast<uint64_t>(acc) << 32) | left_aligned) >> n);
+        const bool flush = total >= 32u;
+        if (flush) {
+            const uint32_t be = bswap32(word);
+            const uint32_t at = pos < kSlot - kHdr - 4u ? pos : kSlot - kHdr - 4u;
+            memcpy(base + (body_off + at), &be, 4);
+        }
+        // after a flush the total-32 youngest bits stay, all of them from `bits`
+        const uint32_t kept = bits & ((1u << (total & 31u)) - 1u);
+        const uint32_t grown = (acc << (count & 31u)) | bits;
+        acc = flush ? kept : grown;
+        pos += flush ? 4u : 0u;
+        n = total & 31u;
+    }
+
+    // `first` (one bit), then `count` copies of its complement; count is
+    // unbounded in principle.  One put() call site, deliberately not unrolled:
+    // this is the rare path.
+    GPUAR_LANE void put_bit_then_run(uint32_t first, uint32_t count) {
+        const uint32_t ones = first - 1u;                       // complement of `first`, replicated
+        uint32_t remaining = count + 1u;
+        uint32_t lead = first;                                  // the very first bit emitted
+#pragma clang loop unroll(disable) vectorize(disable)
+        while (remaining) {
+            const uint32_t c = remaining < 32u ? remaining : 32u;
+            const uint32_t mask = c == 32u ? 0xFFFFFFFFu : ((1u << c) - 1u);
+            // chunk = [lead or complement] followed by c-1 complements
+            const uint32_t chunk = ((ones & mask) & ~(1u << (c - 1u))) | (((remaining == count + 1u) ? lead : (first ^ 1u)) << (c - 1u));
+            put(chunk, c);
+            remaining -= c;
+        }
     }
 
     GPUAR_LANE void step(uint32_t cums, Recip rc) {
@@ -359,34 +457,38 @@ struct CoderLane {
         // underflow run: from bit 14 down, lo has 1 and hi has 0  <=>  a1 & b1
         const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
         p = ((a1 << u) & 0x7FFFu) | (((b1 << u) & 0x7FFFu) << 16);
-        if (e) {
-            const uint32_t agreed = a >> (16u - e);           // the e agreed bits (same in lo and hi)
-            const uint32_t em1 = e - 1u;
-            const uint32_t top = agreed >> em1;
-            const uint32_t rest = agreed & ((1u << em1) - 1u);
-            if (pending <= 16u) {
-                // top, then `pending` copies of !top, then rest
-                const uint32_t fill = (1u << pending) - 1u + top;
-                sink.put((fill << em1) | rest, e + pending);
-            } else {
-                sink.put(top, 1u);
-                sink.put_run(top ^ 1u, pending);
-                if (em1) sink.put(rest, em1);
-            }
-            pending = 0;
-        }
-        pending += u;
+        // the e agreed bits (same in lo and hi): top, then `pending` copies of
+        // !top, then the rest.  Branch-free for the usual pending <= 16.
+        const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
+        const uint32_t em1 = (e - 1u) & 31u;
+        const uint32_t top = (agreed >> em1) & 1u;
+        const uint32_t rest = agreed & ((1u << em1) - 1u);
+        const bool shift_out = e != 0u;
+        const bool long_run = shift_out && pending > 16u;     // rare: more than 16 underflow bits owed
+        if (long_run) put_bit_then_run(top, pending);
+        const uint32_t fill = (1u << (pending & 31u)) - 1u + top;
+        const uint32_t bits = long_run ? rest : ((fill << em1) | rest);
+        const uint32_t count = long_run ? em1 : e + pending;
+        put(shift_out ? bits : 0u, shift_out ? count : 0u);
+        pending = (shift_out ? 0u : pending) + u;
     }
 
-    GPUAR_LANE uint32_t finish(uint8_t *slot, uint32_t ulen, bool &overflowed) {
-        const uint32_t b = (p >> 14) & 1u;                    // bit 14 of lo
-        sink.put(b, 1u);
-        sink.put_run(b ^ 1u, pending + 1u);
-        uint32_t clen = sink.close() + kHdr;
-        overflowed = sink.overflow || clen > kSlot;
-        if (overflowed) clen = kSlot;
-        const uint32_t hdr = clen | (ulen << 16);
-        memcpy(slot, &hdr, 4);
+    GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed) {
+        uint8_t *body = base + body_off;
+        const uint32_t bit14 = (p >> 14) & 1u;                // bit 14 of lo (writeRemaining :379-388)
+        put_bit_then_run(bit14, pending + 1u);
+        // zero-pad to a byte boundary and store the tail (writeClose :430-439)
+        const uint32_t tail_bytes = (n + 7u) >> 3;
+        const uint32_t word = n ? (acc << (32u - n)) : 0u;
+        uint32_t clen = pos + tail_bytes + kHdr;
+        overflowed = clen > kSlot;
+        if (overflowed) {
+            clen = kSlot;
+        } else {
+            for (uint32_t k = 0; k < tail_bytes; ++k) body[pos + k] = static_cast<uint8_t>(word >> (24u - 8u * k));
+        }
+        const uint32_t hdr = clen | (ulen << 16);             // u16 LE clen, u16 LE ulen (:525-528)
+        memcpy(body - kHdr, &hdr, 4);
         return clen;
     }
 };

@@ -45,14 +45,16 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         const size_t off = p * kPacket;
         const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
         uint8_t *slot = slots + p * kSlot;
-        InorderModel<1> model;
-        model.col = reinterpret_cast<uint8_t *>(tree.data());
-        model.reset();
+        ModelerLane<1> model;
+        model.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
         CoderLane coder;
-        coder.open(slot);
-        for (uint32_t i = 0; i < len; ++i) coder.step(model.step(in[off + i], 256u + i), kRecip.r[i]);
+        coder.open(slots, static_cast<uint32_t>(p * kSlot));
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t next = i + 1 < len ? in[off + i + 1] : 0u;
+            coder.step(model.step(in[off + i], 256u + i, next), kRecip.r[i]);
+        }
         bool ov;
-        coder.finish(slot, len, ov);
+        coder.finish(len, ov);
         any_overflow |= ov ? 1 : 0;
     }
     return any_overflow;

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3: N encode + N decode launches over a resident buffer.
+
+    rocprofv3 --kernel-trace --stats -d OUT -- python3 tools/prof_run.py [--gib 1] [--reps 3]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=1.0)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--kind", default="uniform")
+    ap.add_argument("--only", default="both", choices=["both", "encode", "decode"])
+    a = ap.parse_args()
+    import torch
+    from gpuar_amd import hip as H
+    n = int(a.gib * (1 << 30)) // 8192 * 8192
+    d_in = H.generate(a.kind, 42, n)
+    npk = H.packet_count(n)
+    d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(npk * H.PACKET, dtype=torch.uint8, device="cuda")
+    H.encode(d_in, d_slots)
+    for _ in range(a.reps):
+        if a.only in ("both", "encode"):
+            H.encode(d_in, d_slots)
+        if a.only in ("both", "decode"):
+            H.decode(d_slots, npk, d_out)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out[:n], d_in) or a.only == "encode"
+    print("prof_run ok", n, "bytes", npk, "packets")
+
+
+if __name__ == "__main__":
+    main()
