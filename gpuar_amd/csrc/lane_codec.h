@@ -20,8 +20,16 @@
 #define GPUAR_LANE __device__ __forceinline__
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
+// quotient ESTIMATE (v_cvt, v_rcp_f32, v_mul, v_cvt): within 1 of floor(num/den)
+// for num < 2^30, den <= 2^16, quotient < 2^14; the callers correct it exactly
 #define GPUAR_RCP_QUOT(num, den) \
-    static_cast<uint32_t>(__uint2float_rz(num) * __frcp_rn(__uint2float_rn(den)))
+    static_cast<uint32_t>(static_cast<float>(num) * __builtin_amdgcn_rcpf(static_cast<float>(den)))
+// keep values in registers at this point: stops hipcc from sinking LDS reads
+// into the branches that consume them (which would serialise the round trips)
+#define GPUAR_PIN7(a, b, c, d, e, f, g) \
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g))
+// materialise x here and keep memory operations on their side of this point
+#define GPUAR_PIN_ORDER(x) asm volatile("" : "+v"(x) : : "memory")
 #else
 #define GPUAR_LANE inline
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
@@ -30,6 +38,8 @@
 // rotating schedule, so the exact correction that follows it is exercised
 #define GPUAR_RCP_QUOT(num, den) \
     (static_cast<uint32_t>((num) / (den)) + (((num) % 3u) == 0u ? 1u : (((num) % 3u) == 1u && (num) >= (den) ? 0xFFFFFFFFu : 0u)))
+#define GPUAR_PIN7(a, b, c, d, e, f, g) ((void)0)
+#define GPUAR_PIN_ORDER(x) ((void)0)
 #endif
 
 namespace gpuar {
@@ -618,6 +628,203 @@ struct DecoderLane {
     }
 
     // bytes of a packet whose length is not a multiple of 4
+    GPUAR_LANE void finish(uint8_t *out) {
+        for (uint32_t b = ulen & ~3u; b < ulen; ++b) out[b] = static_cast<uint8_t>(outword >> (8u * (b & 3u)));
+    }
+};
+
+// ===========================================================================
+// Decoder, second form: the symbol search touches LDS in two round trips
+// instead of eight.  Depths 0 and 1 of the left-count tree live in registers;
+// depths 2..4 and 5..7 are stored as 3-level subtrees of 7 consecutive rows
+// [a | b0 b1 | c0 c1 c2 c3], so one address plus seven immediate offsets
+// fetches everything the next three decisions can need, and those decisions
+// are then taken in registers.  Same counts, same sums, same symbols as
+// ModelTree::decode_step.
+//   rows  0..27   : 4 subtrees rooted at the depth-2 nodes (index = top 2 bits)
+//   rows 28..251  : 32 subtrees rooted at the depth-5 nodes (index = top 5 bits)
+// ===========================================================================
+template <uint32_t kRowShift>
+struct SubtreeModel {
+    uint8_t *col;                       // this lane's column; row r at col + (r << kRowShift)
+    uint32_t root, half0, half1;        // depth 0; depth 1 under root's left / right child
+
+    static constexpr uint32_t kRow = 1u << kRowShift;
+
+    GPUAR_LANE uint16_t *row(uint32_t byte_off) const { return reinterpret_cast<uint16_t *>(col + byte_off); }
+
+    GPUAR_LANE void reset() {
+        root = 128u;
+        half0 = half1 = 64u;
+#pragma unroll 1
+        for (uint32_t r = 0; r < 252u; ++r) {
+            const uint32_t within = r < 28u ? r % 7u : (r - 28u) % 7u;       // 0 | 1,2 | 3..6
+            const uint32_t depth_in = within == 0u ? 0u : (within < 3u ? 1u : 2u);
+            const uint32_t top = r < 28u ? 32u : 4u;                          // depth 2 / depth 5 value
+            *row(r << kRowShift) = static_cast<uint16_t>(top >> depth_in);
+        }
+    }
+
+    // three decisions inside the subtree whose first row is at byte offset
+    // `at`; updates t / below / span and the three path nodes, returns the
+    // three decision bits (first decision = bit 2)
+    GPUAR_LANE uint32_t descend3(uint32_t at, uint32_t &t, uint32_t &below, uint32_t &span) {
+        uint32_t a = *row(at);
+        uint32_t b0 = *row(at + 1u * kRow), b1 = *row(at + 2u * kRow);
+        uint32_t c0 = *row(at + 3u * kRow), c1 = *row(at + 4u * kRow);
+        uint32_t c2 = *row(at + 5u * kRow), c3 = *row(at + 6u * kRow);
+        GPUAR_PIN7(a, b0, b1, c0, c1, c2, c3);        // all seven in flight together: one LDS round trip
+        const bool ra = t >= a;
+        t -= ra ? a : 0u;
+        below += ra ? a : 0u;
+        span = ra ? span - a : a;
+        const uint32_t b = ra ? b1 : b0;
+        const uint32_t cl = ra ? c2 : c0, ch = ra ? c3 : c1;
+        const bool rb = t >= b;
+        t -= rb ? b : 0u;
+        below += rb ? b : 0u;
+        span = rb ? span - b : b;
+        const uint32_t c = rb ? ch : cl;
+        const bool rc = t >= c;
+        t -= rc ? c : 0u;
+        below += rc ? c : 0u;
+        span = rc ? span - c : c;
+        const uint32_t ia = ra ? 1u : 0u, ib = rb ? 1u : 0u, ic = rc ? 1u : 0u;
+        *row(at) = static_cast<uint16_t>(a + (ia ^ 1u));
+        *row(at + ((1u + ia) << kRowShift)) = static_cast<uint16_t>(b + (ib ^ 1u));
+        *row(at + ((3u + 2u * ia + ib) << kRowShift)) = static_cast<uint16_t>(c + (ic ^ 1u));
+        return (ia << 2) | (ib << 1) | ic;
+    }
+
+    GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
+        uint32_t t = target, below = 0, span = total;
+        const bool r0 = t >= root;
+        t -= r0 ? root : 0u;
+        below = r0 ? root : 0u;
+        span = r0 ? span - root : root;
+        root += r0 ? 0u : 1u;
+        const uint32_t h = r0 ? half1 : half0;
+        const bool r1 = t >= h;
+        t -= r1 ? h : 0u;
+        below += r1 ? h : 0u;
+        span = r1 ? span - h : h;
+        half0 += (!r0 && !r1) ? 1u : 0u;
+        half1 += (r0 && !r1) ? 1u : 0u;
+        const uint32_t top2 = (r0 ? 2u : 0u) | (r1 ? 1u : 0u);
+        const uint32_t mid = descend3((top2 * 7u) << kRowShift, t, below, span);
+        const uint32_t top5 = (top2 << 3) | mid;
+        const uint32_t low = descend3((28u + top5 * 7u) << kRowShift, t, below, span);
+        cum_lo = below;
+        cum_hi = below + span;
+        return (top5 << 3) | low;
+    }
+};
+
+// Decoder lane built on SubtreeModel, with a leaner bit reader: two aligned
+// big-endian dwords (w0:w1) hold the stream at the current position, a third
+// is in flight; one funnel shift per symbol exposes the next 32 bits.
+template <uint32_t kRowShift>
+struct DecoderLane2 {
+    SubtreeModel<kRowShift> model;
+    uint32_t w0, w1;           // two consecutive stream dwords, big-endian order restored
+    uint32_t ahead;            // the dword after w1, still as loaded (swapped only when it moves up,
+                               // so the wait for its load lands a whole dword of bits later)
+    uint32_t bit;              // bits of w0 already consumed (0..31)
+    const uint8_t *next;       // address of the dword after `ahead` (4-byte aligned)
+    const uint8_t *limit;
+    uint32_t lo, hi, code;
+    uint32_t ulen;
+    uint32_t outword;
+    bool bad;
+
+    // An aligned dword that holds at least one readable byte never crosses a
+    // page, so it is loaded whole; bytes past `limit` in it are don't-cares
+    // (a well-formed packet decodes the same whatever follows it).
+    GPUAR_LANE uint32_t fetch() {
+        uint32_t w = 0;
+        if (next < limit) memcpy(&w, next, 4);
+        next += 4;
+        return w;
+    }
+
+    // the next 32 stream bits, left-aligned
+    GPUAR_LANE uint32_t peek() const {
+        return static_cast<uint32_t>(((static_cast<uint64_t>(w0) << 32) | w1) >> (32u - bit));
+    }
+    GPUAR_LANE void skip(uint32_t count) {      // count <= 32
+        bit += count;
+        if (bit >= 32u) {
+            bit -= 32u;
+            w0 = w1;
+            w1 = bswap32(ahead);
+            // consume the OLD prefetched dword before the new load is issued:
+            // otherwise the wait for the old one (vmcnt) also waits for the new one
+            GPUAR_PIN_ORDER(w1);
+            ahead = fetch();
+        }
+    }
+
+    GPUAR_LANE void open(uint8_t *col, const uint8_t *pkt, const uint8_t *lim, bool live) {
+        model.col = col;
+        model.reset();
+        ulen = 0;
+        bad = false;
+        outword = 0;
+        if (live) {
+            const uint32_t clen = pkt[0] | (static_cast<uint32_t>(pkt[1]) << 8);
+            ulen = pkt[2] | (static_cast<uint32_t>(pkt[3]) << 8);
+            if (ulen > kPacket || clen < kHdr) {   // the reference would run off its buffers here
+                bad = true;
+                ulen = 0;
+            }
+        }
+        const uint8_t *body = live ? pkt + kHdr : pkt;
+        const uint32_t misalign = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(body) & 3u);
+        next = body - misalign;
+        limit = live ? lim : pkt;
+        w0 = bswap32(fetch());
+        w1 = bswap32(fetch());
+        ahead = fetch();
+        bit = 8u * misalign;
+        lo = 0;
+        hi = 0xFFFFu;
+        code = peek() >> 16;    // initializeDecoder :582-603
+        skip(16u);
+    }
+
+    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
+        const uint32_t total = 256u + i;
+        const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
+        const uint32_t num = (((code - lo) & 0xFFFFu) + 1u) * total - 1u;
+        uint32_t q = GPUAR_RCP_QUOT(num, range);
+        int32_t rem = static_cast<int32_t>(num - q * range);
+        if (rem < 0) {
+            --q;
+            rem += static_cast<int32_t>(range);
+        }
+        if (rem >= static_cast<int32_t>(range)) ++q;
+        if (q >= total) {        // no symbol owns this code value (:873-877): stop this lane
+            bad = true;
+            ulen = i;
+            return;
+        }
+        uint32_t cum_lo, cum_hi;
+        const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
+        outword |= sym << (8u * (i & 3u));
+        if ((i & 3u) == 3u) {
+            memcpy(out + (i & ~3u), &outword, 4);
+            outword = 0;
+        }
+        narrow(lo, hi, cum_lo, cum_hi, rc);
+        const Renorm r = renorm_split(lo, hi);
+        const uint32_t fresh = peek();                         // e + u <= 31 bits are needed
+        const uint32_t e_bits = r.e ? fresh >> (32u - r.e) : 0u;
+        const uint32_t u_bits = r.u ? (fresh << r.e) >> (32u - r.u) : 0u;
+        code = ((code << r.e) | e_bits) & 0xFFFFu;
+        if (r.u) code = (((code << r.u) ^ 0x8000u) | u_bits) & 0xFFFFu;
+        skip(r.e + r.u);
+    }
+
     GPUAR_LANE void finish(uint8_t *out) {
         for (uint32_t b = ulen & ~3u; b < ulen; ++b) out[b] = static_cast<uint8_t>(outword >> (8u * (b & 3u)));
     }

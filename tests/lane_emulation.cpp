@@ -78,6 +78,23 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
     return bad;
 }
 
+// Second decoder form (SubtreeModel + DecoderLane2): what the decode kernels run.
+int emu_decode_stream2(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)
+{
+    int bad = 0;
+    std::vector<uint16_t> tree(256);
+    const uint8_t *limit = stream + pkt_offsets[np];
+    for (size_t p = 0; p < np; ++p) {
+        DecoderLane2<1> dec;
+        uint8_t *o = out + p * kPacket;
+        dec.open(reinterpret_cast<uint8_t *>(tree.data()), stream + pkt_offsets[p], limit, true);
+        for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
+        dec.finish(o);
+        bad += dec.bad ? 1 : 0;
+    }
+    return bad;
+}
+
 // Check of the reciprocal table: for every total d, the multiple boundaries
 // k*d-1 and k*d (stepping k by `stride`) plus the largest numerator
 // d*65536-1.  Returns the number of mismatches.

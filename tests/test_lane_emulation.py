@@ -37,6 +37,8 @@ def emu():
     lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
+    lib.emu_decode_stream2.restype = C.c_int
+    lib.emu_decode_stream2.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
     lib.emu_check_recip.argtypes = [C.c_uint32]
     return lib
@@ -61,10 +63,11 @@ def slots_to_stream(slots, npk):
     return stream, np.asarray(offs, dtype=np.uint64)
 
 
-def emu_decode(lib, stream, offs, npk):
+def emu_decode(lib, stream, offs, npk, form=1):
     padded = np.concatenate([stream, np.zeros(16, dtype=np.uint8)])
     out = np.zeros(max(npk, 1) * 8192, dtype=np.uint8)
-    bad = lib.emu_decode_stream(padded.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), npk, out.ctypes.data_as(u8p))
+    fn = lib.emu_decode_stream if form == 1 else lib.emu_decode_stream2
+    bad = fn(padded.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), npk, out.ctypes.data_as(u8p))
     return out, bad
 
 
@@ -96,6 +99,9 @@ def test_lane_codec_matches_reference_fixture(emu, port_oracle, c):
     out, bad = emu_decode(emu, stream, offs, npk)
     assert bad == 0
     assert np.array_equal(out[:data.size], data)
+    out2, bad2 = emu_decode(emu, stream, offs, npk, form=2)      # SubtreeModel + DecoderLane2
+    assert bad2 == 0
+    assert np.array_equal(out2[:data.size], data)
 
 
 def test_lane_codec_random_packets(emu, port_oracle):
@@ -115,6 +121,8 @@ def test_lane_codec_random_packets(emu, port_oracle):
         assert ov2 == 0 and np.array_equal(slots2, slots), trial
         out, bad = emu_decode(emu, stream, offs, npk)
         assert bad == 0 and np.array_equal(out[:n], data), trial
+        out2, bad2 = emu_decode(emu, stream, offs, npk, form=2)
+        assert bad2 == 0 and np.array_equal(out2[:n], data), trial
 
 
 def test_lane_decoder_survives_garbage(emu):
@@ -128,4 +136,6 @@ def test_lane_decoder_survives_garbage(emu):
         out = np.zeros(8192 + 64, dtype=np.uint8)
         out[8192:] = 0xA5
         emu.emu_decode_stream(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
+        assert np.all(out[8192:] == 0xA5)
+        emu.emu_decode_stream2(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
         assert np.all(out[8192:] == 0xA5)
