@@ -104,8 +104,8 @@ def main():
     H.load()
 
     # ---- this rank's shard: contiguous packet range of the global stream ----
-    n = int(args.gib_per_gpu * GIB) // H.PACKET * H.PACKET
-    offset = rank * n
+    from gpuar_amd import sharding
+    offset, n = sharding.weak_shard(int(args.gib_per_gpu * GIB), rank)
     npk = H.packet_count(n)
     d_in = H.generate(args.kind, args.seed, n, offset=offset, device=dev)
     d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device=dev)

@@ -201,7 +201,18 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, co
     DecoderLane2<7> dec;
     dec.open(col, pkt, limit, live);
     const uint32_t len_max = wave_max(dec.ulen);
-    for (uint32_t i = 0; i < len_max; ++i) {
+    const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
+    // whole groups of 4 symbols that every lane decodes: no per-lane predicate,
+    // one dword store and one 32-byte scalar load of reciprocals per group
+    uint32_t i = 0;
+    for (; i + 4u <= len_min; i += 4u) {
+        Recip rc[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[i + j];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) dec.step(i + j, rc[j], out);
+    }
+    for (; i < len_max; ++i) {              // the ragged rest (the file's last packet, or a partial wavefront)
         const Recip rc = g_recip.r[i];
         if (i < dec.ulen) dec.step(i, rc, out);
     }

@@ -1,0 +1,185 @@
+// cpu_compressor.cpp -- host packet loop of `gpuar --host`
+// (what src/cpu_compressor.cpp:10-206 does), running the same per-lane codec
+// source the GPU kernels run (../lane_codec.h compiled for the host).  This is
+// an explicit user-selected mode, as in the reference; it is never a fallback
+// of the GPU path.
+#include "cpu_compressor.hpp"
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "../lane_codec.h"
+#include "file_header.hpp"
+
+namespace gip {
+
+namespace {
+
+const gpuar::RecipTable kRecip = gpuar::RecipTable();
+constexpr size_t kBatchPackets = 4096;   // 32 MiB of input per batch
+
+size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
+    uint16_t tree[gpuar::kTreeRows];
+    gpuar::EncoderLane<1> enc;
+    enc.open(tree, slot);
+    for (uint32_t i = 0; i < len; ++i) enc.step(in[i], i, kRecip.r[i]);
+    bool overflowed = false;
+    const uint32_t clen = enc.finish(slot, len, overflowed);
+    if (overflowed) throw std::runtime_error("a packet outgrew its 8704-byte slot");
+    return clen;
+}
+
+size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
+    uint16_t tree[gpuar::kTreeRows];
+    gpuar::DecoderLane<1> dec;
+    dec.open(tree, pkt, limit, true);
+    for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], out);
+    dec.finish(out);
+    if (dec.bad) throw std::runtime_error("Incorrect file format");
+    return dec.ulen;
+}
+
+template <typename F>
+void for_each_packet(size_t n, unsigned threads, F &&f) {
+    if (threads <= 1 || n < 2) {
+        for (size_t p = 0; p < n; ++p) f(p);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::exception_ptr failure;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            try {
+                for (size_t p = t; p < n; p += threads) f(p);
+            } catch (...) {
+                failure = std::current_exception();
+            }
+        });
+    for (auto &th : pool) th.join();
+    if (failure) std::rethrow_exception(failure);
+}
+
+}  // namespace
+
+CPUCompressor::CPUCompressor() {}
+CPUCompressor::~CPUCompressor() {}
+
+CompressionInfo CPUCompressor::compress(ProgressMonitor *monitor) {
+    CompressionInfo info;
+    monitor->reset();
+    process_timer.reset();
+    io_timer.reset();
+    io_timer.start();
+    openFiles();
+    info.uncompressedFileSize = getFileSize(openFile);
+    if (std::fseek(saveFile, FileHeader::HEADER_LENGTH, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
+    io_timer.stop();
+    info.compressedFileSize = FileHeader::HEADER_LENGTH;
+
+    const unsigned nthreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    std::vector<uint8_t> in(kBatchPackets * gpuar::kPacket + 16), slots(kBatchPackets * gpuar::kSlot);
+    std::vector<uint32_t> clen(kBatchPackets);
+    try {
+        for (;;) {
+            io_timer.start();
+            const size_t got = std::fread(in.data(), 1, kBatchPackets * gpuar::kPacket, openFile);
+            io_timer.stop();
+            if (got == 0) break;
+            const size_t np = (got + gpuar::kPacket - 1) / gpuar::kPacket;
+            process_timer.start();     // model init + codec only, as src/cpu_compressor.cpp:157-161
+            for_each_packet(np, nthreads, [&](size_t p) {
+                const size_t off = p * gpuar::kPacket;
+                const uint32_t len = static_cast<uint32_t>(std::min<size_t>(gpuar::kPacket, got - off));
+                clen[p] = static_cast<uint32_t>(encode_one(in.data() + off, len, slots.data() + p * gpuar::kSlot));
+            });
+            process_timer.stop();
+            io_timer.start();
+            for (size_t p = 0; p < np; ++p) {
+                if (std::fwrite(slots.data() + p * gpuar::kSlot, clen[p], 1, saveFile) != 1)
+                    throw std::runtime_error("Write data to file failed");
+                info.compressedFileSize += clen[p];
+            }
+            io_timer.stop();
+            info.processedUncompressedSize += got;
+            monitor->updateProgress(&info);
+        }
+        io_timer.start();
+        FileHeader header;
+        header.setCompressedFileSize(info.compressedFileSize);
+        header.setUncompressedFileSize(info.uncompressedFileSize);
+        if (std::fseek(saveFile, 0, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
+        if (std::fwrite(header.getData(), FileHeader::HEADER_LENGTH, 1, saveFile) != 1)
+            throw std::runtime_error("Write data to file failed");
+        closeFiles();
+        io_timer.stop();
+    } catch (...) {
+        closeFiles();
+        throw;
+    }
+    info.processTime = process_timer.value();
+    info.ioTime = io_timer.value();
+    return info;
+}
+
+CompressionInfo CPUCompressor::decompress(ProgressMonitor *monitor) {
+    CompressionInfo info;
+    monitor->reset();
+    process_timer.reset();
+    io_timer.reset();
+    io_timer.start();
+    openFiles();
+    FileHeader header;
+    const size_t fileSize = getFileSize(openFile);
+    try {
+        if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
+            throw std::runtime_error("Incorrect file format");
+        info = header.getInfo();
+        std::vector<uint8_t> stream(fileSize - FileHeader::HEADER_LENGTH + 16);
+        const size_t n_stream = fileSize - FileHeader::HEADER_LENGTH;
+        if (n_stream && std::fread(stream.data(), 1, n_stream, openFile) != n_stream)
+            throw std::runtime_error("Invalid file length");
+        io_timer.stop();
+
+        // the serial header walk of src/cpu_compressor.cpp:47-56: off += clen
+        std::vector<size_t> offsets;
+        for (size_t off = 0; off < n_stream;) {
+            if (n_stream - off < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
+            const size_t c = stream[off] | (static_cast<size_t>(stream[off + 1]) << 8);
+            if (c < gpuar::kHdr || c > n_stream - off) throw std::runtime_error("Incorrect file format");
+            offsets.push_back(off);
+            off += c;
+        }
+        const unsigned nthreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+        std::vector<uint8_t> out(kBatchPackets * gpuar::kPacket);
+        std::vector<uint32_t> ulen(kBatchPackets);
+        for (size_t first = 0; first < offsets.size(); first += kBatchPackets) {
+            const size_t np = std::min(kBatchPackets, offsets.size() - first);
+            process_timer.start();
+            for_each_packet(np, nthreads, [&](size_t p) {
+                ulen[p] = static_cast<uint32_t>(decode_one(stream.data() + offsets[first + p], stream.data() + n_stream,
+                                                           out.data() + p * gpuar::kPacket));
+            });
+            process_timer.stop();
+            io_timer.start();
+            for (size_t p = 0; p < np; ++p) {
+                if (ulen[p] && std::fwrite(out.data() + p * gpuar::kPacket, ulen[p], 1, saveFile) != 1)
+                    throw std::runtime_error("Write raw data to file failed");
+                info.processedUncompressedSize += ulen[p];
+            }
+            io_timer.stop();
+            monitor->updateProgress(&info);
+        }
+        io_timer.start();
+        closeFiles();
+        io_timer.stop();
+    } catch (...) {
+        closeFiles();
+        throw;
+    }
+    info.processTime = process_timer.value();
+    info.ioTime = io_timer.value();
+    return info;
+}
+
+}  // namespace gip

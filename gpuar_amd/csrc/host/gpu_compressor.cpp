@@ -1,0 +1,313 @@
+#include "gpu_compressor.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+#include "file_header.hpp"
+#include "gpuar_hip.h"
+
+namespace gip {
+
+namespace {
+
+constexpr size_t kPacket = GPUAR_PACKET_BYTES;
+constexpr size_t kSlot = GPUAR_SLOT_BYTES;
+
+void hip_check(hipError_t e, const char *what) {
+    // same message shape as src/gpu_compressor.cpp:189-192
+    if (e != hipSuccess) throw std::runtime_error(std::string("Fail to execute kernel code: ") + what + ": " + hipGetErrorString(e));
+}
+void gpuar_check(int code, const char *what) {
+    if (code != GPUAR_OK) throw std::runtime_error(std::string("Fail to execute kernel code: ") + what + ": " + gpuar_hip_error_string(code));
+}
+
+}  // namespace
+
+// Everything one GPU needs for one round of `cap` packets.
+struct GPUCompressor::DeviceBuffers {
+    int device = 0;
+    size_t cap = 0;                 // packets
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    uint8_t *d_plain = nullptr;     // cap * 8192
+    uint8_t *d_slots = nullptr;     // cap * 8704
+    uint8_t *d_stream = nullptr;    // cap * 8704 (+16)
+    uint64_t *d_offsets = nullptr;  // cap + 1
+    uint8_t *h_plain = nullptr;     // pinned, cap * 8192
+    uint8_t *h_stream = nullptr;    // pinned, cap * 8704 (+16)
+    uint64_t *h_offsets = nullptr;  // pinned, cap + 1
+    // per-round results
+    size_t n_plain = 0, n_packets = 0, n_stream = 0;
+    float kernel_ms = 0;
+    std::exception_ptr failure;
+
+    void allocate(int dev, size_t packets) {
+        device = dev;
+        cap = packets;
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+        hip_check(hipEventCreate(&t0), "hipEventCreate");
+        hip_check(hipEventCreate(&t1), "hipEventCreate");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_plain), cap * kPacket), "hipMalloc");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_slots), cap * kSlot), "hipMalloc");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_stream), cap * kSlot + 16), "hipMalloc");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_offsets), (cap + 1) * sizeof(uint64_t)), "hipMalloc");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_plain), cap * kPacket, hipHostMallocDefault), "hipHostMalloc");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_stream), cap * kSlot + 16, hipHostMallocDefault), "hipHostMalloc");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_offsets), (cap + 1) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
+    }
+    void release() {
+        if (!cap) return;
+        (void)hipSetDevice(device);
+        (void)hipFree(d_plain);
+        (void)hipFree(d_slots);
+        (void)hipFree(d_stream);
+        (void)hipFree(d_offsets);
+        (void)hipHostFree(h_plain);
+        (void)hipHostFree(h_stream);
+        (void)hipHostFree(h_offsets);
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        (void)hipStreamDestroy(stream);
+        cap = 0;
+    }
+
+    // h_plain[0..n_plain) -> h_stream[0..n_stream), h_offsets[0..n_packets]
+    void encodeRound() {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        n_packets = (n_plain + kPacket - 1) / kPacket;
+        hip_check(hipMemcpyAsync(d_plain, h_plain, n_plain, hipMemcpyHostToDevice, stream), "H2D");
+        hip_check(hipEventRecord(t0, stream), "event");
+        gpuar_check(gpuar_hip_encode(d_plain, n_plain, d_slots, stream), "gpuar_hip_encode");
+        gpuar_check(gpuar_hip_compact(d_slots, n_packets, d_stream, d_offsets, stream), "gpuar_hip_compact");
+        hip_check(hipEventRecord(t1, stream), "event");
+        hip_check(hipMemcpyAsync(h_offsets, d_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "D2H");
+        hip_check(hipStreamSynchronize(stream), "sync");
+        n_stream = static_cast<size_t>(h_offsets[n_packets]);
+        hip_check(hipMemcpyAsync(h_stream, d_stream, n_stream, hipMemcpyDeviceToHost, stream), "D2H");
+        hip_check(hipStreamSynchronize(stream), "sync");
+        hip_check(hipEventElapsedTime(&kernel_ms, t0, t1), "event");
+        uint32_t flags = 0;
+        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
+        if (flags & GPUAR_STATUS_SLOT_OVERFLOW) throw std::runtime_error("a packet outgrew its 8704-byte slot");
+    }
+
+    // h_stream[0..n_stream) with h_offsets[0..n_packets] -> h_plain[0..n_packets*8192)
+    void decodeRound() {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipMemcpyAsync(d_stream, h_stream, n_stream, hipMemcpyHostToDevice, stream), "H2D");
+        hip_check(hipMemcpyAsync(d_offsets, h_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "H2D");
+        hip_check(hipEventRecord(t0, stream), "event");
+        gpuar_check(gpuar_hip_decode_stream(d_stream, d_offsets, n_packets, d_plain, stream), "gpuar_hip_decode_stream");
+        hip_check(hipEventRecord(t1, stream), "event");
+        hip_check(hipMemcpyAsync(h_plain, d_plain, n_packets * kPacket, hipMemcpyDeviceToHost, stream), "D2H");
+        hip_check(hipStreamSynchronize(stream), "sync");
+        hip_check(hipEventElapsedTime(&kernel_ms, t0, t1), "event");
+        uint32_t flags = 0;
+        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
+        if (flags & GPUAR_STATUS_BAD_PACKET) throw std::runtime_error("Incorrect file format");
+    }
+};
+
+GPUCompressor::GPUCompressor() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw std::runtime_error("No HIP device found (use --host to run the codec on the CPU)");
+    devices.push_back(0);
+    initConstantRange();     // kept for parity with src/gpu_compressor.cpp:19; a no-op for these kernels
+}
+
+GPUCompressor::~GPUCompressor() { releaseBuffers(); }
+
+void GPUCompressor::releaseBuffers() {
+    for (DeviceBuffers *b : buffers) {
+        b->release();
+        delete b;
+    }
+    buffers.clear();
+}
+
+void GPUCompressor::ensureBuffers() {
+    if (buffers.size() == devices.size() && !buffers.empty() && buffers[0]->cap == batchPackets) return;
+    releaseBuffers();
+    for (int dev : devices) {
+        DeviceBuffers *b = new DeviceBuffers();
+        buffers.push_back(b);
+        b->allocate(dev, batchPackets);
+    }
+}
+
+void GPUCompressor::chooseDevice(const int id) {
+    int count = 0;
+    hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    if (id < 0 || id >= count) throw std::runtime_error("No such HIP device: " + std::to_string(id));
+    releaseBuffers();
+    devices.assign(1, id);
+}
+
+void GPUCompressor::useDevices(const int n) {
+    int count = 0;
+    hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    if (n < 1 || n > count) throw std::runtime_error("Asked for " + std::to_string(n) + " GPUs, " + std::to_string(count) + " visible");
+    releaseBuffers();
+    devices.clear();
+    for (int d = 0; d < n; ++d) devices.push_back(d);
+}
+
+namespace {
+template <typename F>
+void run_on_each(std::vector<GPUCompressor *> &, F &&) {}
+}  // namespace
+
+CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
+    CompressionInfo info;
+    monitor->reset();
+    process_timer.reset();
+    io_timer.reset();
+    io_timer.start();
+    openFiles();
+    double kernel_ms_total = 0;
+    try {
+        ensureBuffers();
+        info.uncompressedFileSize = getFileSize(openFile);
+        if (std::fseek(saveFile, FileHeader::HEADER_LENGTH, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
+        info.compressedFileSize = FileHeader::HEADER_LENGTH;
+        const size_t G = buffers.size();
+        size_t remaining = info.uncompressedFileSize;
+        while (remaining > 0) {
+            // contiguous packet ranges, device order = file order
+            const size_t round_bytes = std::min(remaining, G * batchPackets * kPacket);
+            const size_t round_packets = (round_bytes + kPacket - 1) / kPacket;
+            const size_t per_dev = ((round_packets + G - 1) / G + 63) / 64 * 64;      // whole wavefronts
+            size_t given = 0;
+            for (DeviceBuffers *b : buffers) {
+                b->n_plain = std::min(round_bytes - given, per_dev * kPacket);
+                if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
+                    throw std::runtime_error("Read input file failed");
+                given += b->n_plain;
+            }
+            std::vector<std::thread> workers;
+            for (DeviceBuffers *b : buffers)
+                if (b->n_plain) workers.emplace_back([b] {
+                    try {
+                        b->failure = nullptr;
+                        b->encodeRound();
+                    } catch (...) {
+                        b->failure = std::current_exception();
+                    }
+                });
+            for (auto &w : workers) w.join();
+            float slowest = 0;
+            for (DeviceBuffers *b : buffers) {
+                if (!b->n_plain) continue;
+                if (b->failure) std::rethrow_exception(b->failure);
+                slowest = std::max(slowest, b->kernel_ms);
+                if (b->n_stream && std::fwrite(b->h_stream, 1, b->n_stream, saveFile) != b->n_stream)
+                    throw std::runtime_error("Write compressed data to output file failed");
+                info.compressedFileSize += b->n_stream;
+                info.processedUncompressedSize += b->n_plain;
+            }
+            kernel_ms_total += slowest;
+            remaining -= round_bytes;
+            monitor->updateProgress(&info);
+        }
+        FileHeader header;
+        header.setCompressedFileSize(info.compressedFileSize);
+        header.setUncompressedFileSize(info.uncompressedFileSize);
+        if (std::fseek(saveFile, 0, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
+        if (std::fwrite(header.getData(), FileHeader::HEADER_LENGTH, 1, saveFile) != 1)
+            throw std::runtime_error("Write data to file failed");
+        closeFiles();
+    } catch (...) {
+        closeFiles();
+        throw;
+    }
+    io_timer.stop();
+    // "Compute time" = kernels + their sync, as src/gpu_compressor.cpp:184-194; the rest is I/O
+    info.processTime = kernel_ms_total;
+    info.ioTime = std::max(0.0, io_timer.value() - kernel_ms_total);
+    return info;
+}
+
+CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
+    CompressionInfo info;
+    monitor->reset();
+    process_timer.reset();
+    io_timer.reset();
+    io_timer.start();
+    openFiles();
+    double kernel_ms_total = 0;
+    try {
+        ensureBuffers();
+        FileHeader header;
+        const size_t fileSize = getFileSize(openFile);
+        if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
+            throw std::runtime_error("Incorrect file format");
+        info = header.getInfo();
+        const size_t G = buffers.size();
+        size_t file_pos = FileHeader::HEADER_LENGTH;
+        uint8_t hdr[GPUAR_PACKET_HEADER_BYTES];
+        bool more = file_pos < fileSize;
+        while (more) {
+            // fill each device with up to batchPackets packets, walking `off += clen`
+            // through the file like src/gpu_compressor.cpp:299-312
+            for (DeviceBuffers *b : buffers) {
+                b->n_packets = 0;
+                b->n_stream = 0;
+                b->h_offsets[0] = 0;
+                while (more && b->n_packets < b->cap) {
+                    if (std::fread(hdr, sizeof hdr, 1, openFile) != 1) throw std::runtime_error("Incorrect file format");
+                    const size_t clen = getPacketSize(hdr);
+                    if (clen < sizeof hdr || clen > kSlot || file_pos + clen > fileSize) throw std::runtime_error("Invalid file length");
+                    std::memcpy(b->h_stream + b->n_stream, hdr, sizeof hdr);
+                    if (clen > sizeof hdr && std::fread(b->h_stream + b->n_stream + sizeof hdr, 1, clen - sizeof hdr, openFile) != clen - sizeof hdr)
+                        throw std::runtime_error("Invalid file length");
+                    b->n_stream += clen;
+                    b->h_offsets[++b->n_packets] = b->n_stream;
+                    file_pos += clen;
+                    more = file_pos < fileSize;
+                }
+            }
+            (void)G;
+            std::vector<std::thread> workers;
+            for (DeviceBuffers *b : buffers)
+                if (b->n_packets) workers.emplace_back([b] {
+                    try {
+                        b->failure = nullptr;
+                        b->decodeRound();
+                    } catch (...) {
+                        b->failure = std::current_exception();
+                    }
+                });
+            for (auto &w : workers) w.join();
+            float slowest = 0;
+            for (DeviceBuffers *b : buffers) {
+                if (!b->n_packets) continue;
+                if (b->failure) std::rethrow_exception(b->failure);
+                slowest = std::max(slowest, b->kernel_ms);
+                // every packet but the file's last one holds 8192 bytes (src/gpu_compressor.cpp:326-331)
+                size_t n = b->n_packets * kPacket;
+                const size_t left = info.uncompressedFileSize - info.processedUncompressedSize;
+                if (n > left) n = left;
+                if (n && std::fwrite(b->h_plain, 1, n, saveFile) != n)
+                    throw std::runtime_error("Write uncompressed data to output file failed");
+                info.processedUncompressedSize += n;
+            }
+            kernel_ms_total += slowest;
+            monitor->updateProgress(&info);
+        }
+        closeFiles();
+    } catch (...) {
+        closeFiles();
+        throw;
+    }
+    io_timer.stop();
+    info.processTime = kernel_ms_total;
+    info.ioTime = std::max(0.0, io_timer.value() - kernel_ms_total);
+    return info;
+}
+
+}  // namespace gip

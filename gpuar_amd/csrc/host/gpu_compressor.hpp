@@ -1,0 +1,44 @@
+// gpu_compressor.hpp -- host pipeline of the GPU path, API as
+// src/gpu_compressor.hpp:8-39 (chooseDevice, getPacketSize, compress,
+// decompress) plus useDevices() for the multi-GPU sharding the north star
+// adds.  Internals are new: bulk pinned transfers, device-side compaction and
+// one host thread per GPU instead of the reference's per-packet memcpys
+// (src/gpu_compressor.cpp:134-171).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "compressor.hpp"
+
+namespace gip {
+
+class GPUCompressor : public Compressor {
+  public:
+    GPUCompressor();                 // throws if no HIP device is visible: there is no CPU fallback
+    ~GPUCompressor() override;
+    CompressionInfo compress(ProgressMonitor *monitor) override;
+    CompressionInfo decompress(ProgressMonitor *monitor) override;
+
+    void chooseDevice(const int id);     // run on exactly this device
+    void useDevices(const int count);    // shard packets over devices 0..count-1
+    int deviceCount() const { return static_cast<int>(devices.size()); }
+
+    // u16 LE packet length at the start of a packet (src/gpu_compressor.hpp:33-36)
+    static unsigned short getPacketSize(const uint8_t *packet) {
+        return static_cast<unsigned short>(packet[0] | (packet[1] << 8));
+    }
+
+    // packets each device takes per round (default 131072 = 1 GiB of input)
+    void setBatchPackets(size_t n) { batchPackets = n; }
+
+  private:
+    struct DeviceBuffers;
+    std::vector<int> devices;
+    std::vector<DeviceBuffers *> buffers;
+    size_t batchPackets = 131072;
+
+    void releaseBuffers();
+    void ensureBuffers();
+};
+
+}  // namespace gip

@@ -1,0 +1,151 @@
+// main.cpp -- the `gpuar` command line (flags and output text of src/main.cpp:59-205).
+//
+//   gpuar c|d --in=F --out=G [--host] [--device=N] [--gpus=K] [--threads=T] [--nointeractive] [--help]
+//
+// Differences from the reference, all on the error side: `--in F` and `--in=F`
+// are both accepted on purpose (the reference's `--in F` works by accident of
+// argv layout), device 0 can be chosen explicitly, a missing GPU is an error
+// unless --host is given (no silent CPU fallback), and failures exit non-zero
+// with a message instead of std::terminate.
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+
+#include "cpu_compressor.hpp"
+#include "gpu_compressor.hpp"
+
+using namespace gip;
+
+namespace {
+
+// flags are matched after stripping leading '-' and case-insensitively, as
+// common/helper_string.h:104-130 does
+bool flag_name_is(const char *arg, const char *name, const char **value) {
+    while (*arg == '-') ++arg;
+    const size_t n = std::strlen(name);
+    for (size_t i = 0; i < n; ++i)
+        if (std::tolower(static_cast<unsigned char>(arg[i])) != name[i]) return false;
+    if (arg[n] == '\0') {
+        *value = nullptr;
+        return true;
+    }
+    if (arg[n] == '=') {
+        *value = arg + n + 1;
+        return true;
+    }
+    return false;
+}
+
+void usage() {
+    std::cout << "Usage: gpuar [options] --in=inputfile --out=outputfile" << std::endl << std::endl;
+    std::cout << "where options inclide:" << std::endl;
+    std::cout << "c             compress input file" << std::endl;
+    std::cout << "d             decompress input file" << std::endl;
+    std::cout << "--in          input file" << std::endl;
+    std::cout << "--out         outputt file" << std::endl;
+    std::cout << "--help        print this help message" << std::endl;
+    std::cout << "--host        execute kernel code on host (cpu mode), otherwise execute kernel code on the GPU" << std::endl;
+    std::cout << "--device      specify GPU device, otherwise use device 0" << std::endl;
+    std::cout << "--gpus        shard the packets over this many GPUs (devices 0..K-1)" << std::endl;
+    std::cout << "--threads     host threads for --host (default 1, 0 = all cores)" << std::endl;
+    std::cout << "--nointeractive no interactive mode" << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    bool decompress = false, host = false, help = argc <= 1;
+    std::string in, out = "output.gip";
+    bool has_in = false;
+    int device = -1, gpus = 0, threads = 1;
+    for (int i = 1; i < argc; ++i) {
+        const char *v = nullptr;
+        auto take = [&](const char **dst) {            // value after '=' or in the next argument
+            if (*dst) return true;
+            if (i + 1 < argc) {
+                *dst = argv[++i];
+                return true;
+            }
+            return false;
+        };
+        if (!std::strcmp(argv[i], "c")) {
+        } else if (!std::strcmp(argv[i], "d")) {
+            decompress = true;
+        } else if (flag_name_is(argv[i], "help", &v)) {
+            help = true;
+        } else if (flag_name_is(argv[i], "host", &v)) {
+            host = true;
+        } else if (flag_name_is(argv[i], "nointeractive", &v)) {
+        } else if (flag_name_is(argv[i], "in", &v)) {
+            if (!take(&v)) break;
+            in = v;
+            has_in = true;
+        } else if (flag_name_is(argv[i], "out", &v)) {
+            if (!take(&v)) break;
+            out = v;
+        } else if (flag_name_is(argv[i], "device", &v)) {
+            if (!take(&v)) break;
+            device = std::atoi(v);
+        } else if (flag_name_is(argv[i], "gpus", &v)) {
+            if (!take(&v)) break;
+            gpus = std::atoi(v);
+        } else if (flag_name_is(argv[i], "threads", &v)) {
+            if (!take(&v)) break;
+            threads = std::atoi(v);
+        } else {
+            std::cerr << "Unknown argument: " << argv[i] << std::endl;
+            return 2;
+        }
+    }
+    if (help) {
+        usage();
+        return 0;
+    }
+    try {
+        if (!has_in) throw std::runtime_error("Please specify the input file name by command: --in filename");
+        ProgressMonitor monitor;
+        std::unique_ptr<Compressor> compressor;
+        if (host) {
+            auto *cpu = new CPUCompressor();
+            cpu->setThreads(static_cast<unsigned>(threads < 0 ? 1 : threads));
+            compressor.reset(cpu);
+            std::cout << "Attention: execute kernel code on host." << std::endl;
+        } else {
+            auto *gpu = new GPUCompressor();
+            compressor.reset(gpu);
+            if (device >= 0) {
+                std::cout << "Choose GPU device: " << device << "." << std::endl;
+                gpu->chooseDevice(device);
+            } else if (gpus > 0) {
+                std::cout << "Shard packets over " << gpus << " GPUs." << std::endl;
+                gpu->useDevices(gpus);
+            }
+        }
+        compressor->setOpenFileName(in);
+        compressor->setSaveFileName(out);
+        CompressionInfo info;
+        if (!decompress) {
+            std::cout << "Start to compress " << in << " to " << out << "." << std::endl;
+            info = compressor->compress(&monitor);
+        } else {
+            std::cout << "Start to decompress " << in << " to " << out << "." << std::endl;
+            info = compressor->decompress(&monitor);
+        }
+        const double ratio = static_cast<double>(info.compressedFileSize) / info.uncompressedFileSize;
+        std::cout << "Complete" << std::endl << std::endl;
+        std::cout << "Statistics: " << std::endl;
+        std::cout << "Uncompressed file size " << info.uncompressedFileSize << " bytes" << std::endl;
+        std::cout << "Compressed file size  " << info.compressedFileSize << " bytes" << std::endl;
+        std::cout << "Compression ratio     " << ratio << std::endl;
+        std::cout << "Compute time          " << info.processTime / 1000 << " s" << std::endl;
+        std::cout << "I/O time              " << info.ioTime / 1000 << " s" << std::endl;
+        std::cout << "Score                 " << (1000 / (std::pow(ratio, 0.6) * std::pow(info.processTime / 1000, 0.4)))
+                  << std::endl;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -2,9 +2,11 @@
 //
 // Compiled by hipcc into the gfx950 kernels (gpuar_kernels.hip), where 64
 // lanes run it in lock step over 64 packets.  The same source also compiles
-// with a host compiler (tests/lane_emulation.cpp) so the closed forms below
-// can be checked against the oracle on a machine without a GPU; that host
-// build is a test harness only and is not linked into any product library.
+// with a host compiler: tests/lane_emulation.cpp checks the closed forms below
+// against the oracle on a machine without a GPU, and host/cpu_compressor.cpp
+// uses it for the explicit `--host` mode of the CLI (the reference's
+// CPUCompressor, src/cpu_compressor.cpp).  The GPU entry points never fall
+// back to it.
 //
 // Semantics follow SURVEY.md section 8(a); reference lines are cited at each
 // function (/root/reference/src/gpuar_kernel.cu unless noted).
@@ -20,6 +22,7 @@
 #define GPUAR_LANE __device__ __forceinline__
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
+#define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
 // quotient ESTIMATE (v_cvt, v_rcp_f32, v_mul, v_cvt): within 1 of floor(num/den)
 // for num < 2^30, den <= 2^16, quotient < 2^14; the callers correct it exactly
 #define GPUAR_RCP_QUOT(num, den) \
@@ -34,10 +37,15 @@
 #define GPUAR_LANE inline
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
-// host stand-in for the estimate only: deliberately off by one both ways on a
+#define GPUAR_MUL24(a, b) ((a) * (b))
+#ifdef GPUAR_LANE_TEST_PERTURB
+// test harness only: the estimate is deliberately off by one both ways on a
 // rotating schedule, so the exact correction that follows it is exercised
 #define GPUAR_RCP_QUOT(num, den) \
     (static_cast<uint32_t>((num) / (den)) + (((num) % 3u) == 0u ? 1u : (((num) % 3u) == 1u && (num) >= (den) ? 0xFFFFFFFFu : 0u)))
+#else
+#define GPUAR_RCP_QUOT(num, den) static_cast<uint32_t>((num) / (den))
+#endif
 #define GPUAR_PIN7(a, b, c, d, e, f, g) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #endif
@@ -141,8 +149,8 @@ struct ModelTree {
 // Interval narrowing (applySymbolRange :256-299); 16-bit state in 32-bit registers.
 GPUAR_LANE void narrow(uint32_t &lo, uint32_t &hi, uint32_t cum_lo, uint32_t cum_hi, Recip rc) {
     const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-    const uint32_t up = div_total(cum_hi * range, rc);
-    const uint32_t dn = div_total(cum_lo * range, rc);
+    const uint32_t up = div_total(GPUAR_MUL24(cum_hi, range), rc);
+    const uint32_t dn = div_total(GPUAR_MUL24(cum_lo, range), rc);
     hi = (lo + up - 1u) & 0xFFFFu;
     lo = (lo + dn) & 0xFFFFu;
 }
@@ -169,6 +177,15 @@ GPUAR_LANE Renorm renorm_split(uint32_t &lo, uint32_t &hi) {
 }
 
 GPUAR_LANE uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// 32-bit store to an address that is 4-byte aligned by construction
+GPUAR_LANE void store32(uint8_t *at, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint32_t *>(at) = v;
+#else
+    memcpy(at, &v, 4);
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // Bit sink: MSB-first bits -> big-endian dwords in the packet slot
@@ -457,8 +474,8 @@ struct CoderLane {
         const uint32_t lo = p & 0xFFFFu;
         const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
         const uint32_t range = above - (p >> 16);             // hi - lo + 1
-        const uint32_t up = div_total((cums >> 16) * range, rc);
-        const uint32_t dn = div_total((cums & 0xFFFFu) * range, rc);
+        const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
+        const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
         const uint32_t a = lo + dn;                           // new lo
         const uint32_t b = above - up;                        // 0xFFFF - new hi
         // e = agreeing MSBs of new lo / new hi = leading ones of a ^ b (16 bit)
@@ -665,57 +682,60 @@ struct SubtreeModel {
         }
     }
 
-    // three decisions inside the subtree whose first row is at byte offset
-    // `at`; updates t / below / span and the three path nodes, returns the
-    // three decision bits (first decision = bit 2)
-    GPUAR_LANE uint32_t descend3(uint32_t at, uint32_t &t, uint32_t &below, uint32_t &span) {
+    // Three decisions inside the subtree whose first row is at byte offset
+    // `at`.  State: `below` = count of symbols left of the current node's
+    // range, `upper` = count of symbols left of its right end; the target is
+    // compared against below + left-count directly, so nothing but these two
+    // bounds is carried down.  Updates the three path nodes; returns the
+    // decision bits (first decision = bit 2).
+    GPUAR_LANE uint32_t descend3(uint32_t at, uint32_t target, uint32_t &below, uint32_t &upper) {
         uint32_t a = *row(at);
         uint32_t b0 = *row(at + 1u * kRow), b1 = *row(at + 2u * kRow);
         uint32_t c0 = *row(at + 3u * kRow), c1 = *row(at + 4u * kRow);
         uint32_t c2 = *row(at + 5u * kRow), c3 = *row(at + 6u * kRow);
         GPUAR_PIN7(a, b0, b1, c0, c1, c2, c3);        // all seven in flight together: one LDS round trip
-        const bool ra = t >= a;
-        t -= ra ? a : 0u;
-        below += ra ? a : 0u;
-        span = ra ? span - a : a;
+        const uint32_t sa = below + a;
+        const bool ra = target >= sa;
+        below = ra ? sa : below;
+        upper = ra ? upper : sa;
         const uint32_t b = ra ? b1 : b0;
         const uint32_t cl = ra ? c2 : c0, ch = ra ? c3 : c1;
-        const bool rb = t >= b;
-        t -= rb ? b : 0u;
-        below += rb ? b : 0u;
-        span = rb ? span - b : b;
+        const uint32_t sb = below + b;
+        const bool rb = target >= sb;
+        below = rb ? sb : below;
+        upper = rb ? upper : sb;
         const uint32_t c = rb ? ch : cl;
-        const bool rc = t >= c;
-        t -= rc ? c : 0u;
-        below += rc ? c : 0u;
-        span = rc ? span - c : c;
+        const uint32_t sc = below + c;
+        const bool rc = target >= sc;
+        below = rc ? sc : below;
+        upper = rc ? upper : sc;
         const uint32_t ia = ra ? 1u : 0u, ib = rb ? 1u : 0u, ic = rc ? 1u : 0u;
-        *row(at) = static_cast<uint16_t>(a + (ia ^ 1u));
-        *row(at + ((1u + ia) << kRowShift)) = static_cast<uint16_t>(b + (ib ^ 1u));
-        *row(at + ((3u + 2u * ia + ib) << kRowShift)) = static_cast<uint16_t>(c + (ic ^ 1u));
+        *row(at) = static_cast<uint16_t>(a + 1u - ia);
+        *row(at + ((1u + ia) << kRowShift)) = static_cast<uint16_t>(b + 1u - ib);
+        *row(at + ((3u + 2u * ia + ib) << kRowShift)) = static_cast<uint16_t>(c + 1u - ic);
         return (ia << 2) | (ib << 1) | ic;
     }
 
+    // the symbol s with cum(s) <= target < cum(s+1); cum_lo = cum(s), cum_hi = cum(s+1)
     GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
-        uint32_t t = target, below = 0, span = total;
-        const bool r0 = t >= root;
-        t -= r0 ? root : 0u;
+        uint32_t below = 0, upper = total;
+        const bool r0 = target >= root;
         below = r0 ? root : 0u;
-        span = r0 ? span - root : root;
-        root += r0 ? 0u : 1u;
+        upper = r0 ? total : root;
         const uint32_t h = r0 ? half1 : half0;
-        const bool r1 = t >= h;
-        t -= r1 ? h : 0u;
-        below += r1 ? h : 0u;
-        span = r1 ? span - h : h;
+        const uint32_t s1 = below + h;
+        const bool r1 = target >= s1;
+        below = r1 ? s1 : below;
+        upper = r1 ? upper : s1;
+        root += r0 ? 0u : 1u;
         half0 += (!r0 && !r1) ? 1u : 0u;
         half1 += (r0 && !r1) ? 1u : 0u;
         const uint32_t top2 = (r0 ? 2u : 0u) | (r1 ? 1u : 0u);
-        const uint32_t mid = descend3((top2 * 7u) << kRowShift, t, below, span);
+        const uint32_t mid = descend3((top2 * 7u) << kRowShift, target, below, upper);
         const uint32_t top5 = (top2 << 3) | mid;
-        const uint32_t low = descend3((28u + top5 * 7u) << kRowShift, t, below, span);
+        const uint32_t low = descend3((28u + top5 * 7u) << kRowShift, target, below, upper);
         cum_lo = below;
-        cum_hi = below + span;
+        cum_hi = upper;
         return (top5 << 3) | low;
     }
 };
@@ -742,7 +762,11 @@ struct DecoderLane2 {
     // (a well-formed packet decodes the same whatever follows it).
     GPUAR_LANE uint32_t fetch() {
         uint32_t w = 0;
+#ifdef GPUAR_DIAG_NOFETCH      // timing experiment only: wrong data, no stream loads
+        w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(next)) * 2654435761u;
+#else
         if (next < limit) memcpy(&w, next, 4);
+#endif
         next += 4;
         return w;
     }
@@ -795,24 +819,25 @@ struct DecoderLane2 {
     GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
         const uint32_t total = 256u + i;
         const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-        const uint32_t num = (((code - lo) & 0xFFFFu) + 1u) * total - 1u;
+        const uint32_t num = GPUAR_MUL24(((code - lo) & 0xFFFFu) + 1u, total) - 1u;
         uint32_t q = GPUAR_RCP_QUOT(num, range);
-        int32_t rem = static_cast<int32_t>(num - q * range);
+        int32_t rem = static_cast<int32_t>(num - GPUAR_MUL24(q & 0xFFFFFFu, range));
         if (rem < 0) {
             --q;
             rem += static_cast<int32_t>(range);
         }
         if (rem >= static_cast<int32_t>(range)) ++q;
-        if (q >= total) {        // no symbol owns this code value (:873-877): stop this lane
-            bad = true;
-            ulen = i;
-            return;
-        }
+        // No symbol owns a code value >= total (:873-877, where the reference
+        // stops decoding the packet).  Such a packet is malformed: flag it and
+        // keep going on a clamped target -- the walk stays inside the tree and
+        // the output inside its 8192 bytes whatever the bits are.
+        bad = bad || q >= total;
+        q = q < total ? q : total - 1u;
         uint32_t cum_lo, cum_hi;
         const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
         outword |= sym << (8u * (i & 3u));
         if ((i & 3u) == 3u) {
-            memcpy(out + (i & ~3u), &outword, 4);
+            store32(out + (i & ~3u), outword);
             outword = 0;
         }
         narrow(lo, hi, cum_lo, cum_hi, rc);

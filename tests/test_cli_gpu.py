@@ -1,0 +1,55 @@
+"""The `gpuar` CLI on the GPU path (C++ GPUCompressor over the C ABI): files must equal the
+reference's --host outputs from byte 20 on, and round-trip."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpuar_amd import synth
+from test_oracle_golden import SURVEY
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gpuar_amd", "bin", "gpuar")
+
+
+def run(*args):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("s", SURVEY["streams"], ids=lambda s: f"{s['kind']}-{s['seed']}-{s['n']}")
+def test_gpu_cli_matches_reference_files(tmp_path, s):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, gip, back = tmp_path / "in.dat", tmp_path / "out.gip", tmp_path / "back.dat"
+    data = synth.generate(s["kind"], s["seed"], s["n"])
+    data.tofile(src)
+    r = run("c", f"--in={src}", f"--out={gip}", "--gpus=1")
+    assert r.returncode == 0, r.stderr
+    assert "Attention" not in r.stdout                     # not the host path
+    blob = open(gip, "rb").read()
+    assert len(blob) == s["gip_bytes"]
+    assert blob[0:3] == b"\x00\x01\x00"
+    assert int.from_bytes(blob[4:12], "little") == s["n"]
+    assert int.from_bytes(blob[12:20], "little") == s["gip_bytes"]
+    assert hashlib.md5(blob[20:]).hexdigest() == s["stream_md5"]
+    r = run("d", f"--in={gip}", f"--out={back}", "--device=0")
+    assert r.returncode == 0, r.stderr
+    assert hashlib.md5(open(back, "rb").read()).hexdigest() == s["input_md5"]
+
+
+def test_gpu_cli_small_batches_and_cross_check_with_host(tmp_path):
+    """Several rounds per file (the multi-round path of GPUCompressor) and host<->GPU interchange."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, g1, g2, back = tmp_path / "in.dat", tmp_path / "gpu.gip", tmp_path / "host.gip", tmp_path / "back.dat"
+    data = synth.zipf(4, 3 * 1024 * 1024 + 12345)
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={g1}").returncode == 0
+    assert run("c", "--host", "--threads=0", f"--in={src}", f"--out={g2}").returncode == 0
+    assert open(g1, "rb").read() == open(g2, "rb").read()          # identical files, header included
+    assert run("d", "--host", "--threads=0", f"--in={g1}", f"--out={back}").returncode == 0
+    assert open(back, "rb").read() == data.tobytes()

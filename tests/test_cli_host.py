@@ -1,0 +1,80 @@
+"""The `gpuar` CLI and the C++ Compressor/CPUCompressor classes behind it (--host mode), on CPU.
+
+Mirrors the reference's own manual check (README.md:12-29: compress, decompress,
+compare) and pins the produced .gip against the reference's outputs: header
+bytes 0-2, 4-7, 12-15 and every byte from offset 20 on.
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpuar_amd import synth
+from test_oracle_golden import SURVEY
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gpuar_amd", "bin", "gpuar")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(CLI):
+        import __graft_entry__ as g
+        g.build()
+    return CLI
+
+
+def run(cli, *args):
+    return subprocess.run([cli, *args], capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("s", [s for s in SURVEY["streams"] if not s.get("slow")],
+                         ids=lambda s: f"{s['kind']}-{s['seed']}-{s['n']}")
+def test_host_cli_matches_reference_files(cli, tmp_path, s):
+    src, gip, back = tmp_path / "in.dat", tmp_path / "out.gip", tmp_path / "back.dat"
+    data = synth.generate(s["kind"], s["seed"], s["n"])
+    data.tofile(src)
+    r = run(cli, "c", "--host", f"--in={src}", f"--out={gip}")
+    assert r.returncode == 0, r.stderr
+    assert "Attention: execute kernel code on host." in r.stdout and "Compression ratio" in r.stdout
+    blob = open(gip, "rb").read()
+    assert len(blob) == s["gip_bytes"]
+    assert blob[0:3] == b"\x00\x01\x00"
+    assert int.from_bytes(blob[4:8], "little") == s["n"]
+    assert int.from_bytes(blob[12:16], "little") == s["gip_bytes"]
+    assert hashlib.md5(blob[20:]).hexdigest() == s["stream_md5"]
+    # `--in F` (space) spelling, multi-threaded decode
+    r = run(cli, "d", "--host", "--threads", "0", "--in", str(gip), "--out", str(back))
+    assert r.returncode == 0, r.stderr
+    assert open(back, "rb").read() == data.tobytes()
+
+
+def test_host_cli_empty_and_errors(cli, tmp_path):
+    src, gip, back = tmp_path / "empty", tmp_path / "e.gip", tmp_path / "e.back"
+    src.write_bytes(b"")
+    assert run(cli, "c", "--host", f"--in={src}", f"--out={gip}").returncode == 0
+    assert len(gip.read_bytes()) == 20                      # header only
+    assert run(cli, "d", "--host", f"--in={gip}", f"--out={back}").returncode == 0
+    assert back.read_bytes() == b""
+    r = run(cli, "c", "--host", f"--in={tmp_path / 'missing'}", f"--out={gip}")
+    assert r.returncode == 1 and "Can not open input file" in r.stderr
+    bad = tmp_path / "bad.gip"
+    bad.write_bytes(b"\x09\x09\x09" + bytes(40))
+    r = run(cli, "d", "--host", f"--in={bad}", f"--out={back}")
+    assert r.returncode == 1 and "Incorrect file format" in r.stderr
+    r = run(cli, "c", "--host")
+    assert r.returncode == 1 and "Please specify the input file name" in r.stderr
+    assert "Usage: gpuar" in run(cli, "--help").stdout
+
+
+def test_gpu_mode_has_no_silent_cpu_fallback(cli, tmp_path):
+    """Without --host the CLI must use the GPU or fail loudly (the reference falls back silently, src/main.cpp:142)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    src = tmp_path / "in.dat"
+    src.write_bytes(b"hello")
+    r = run(cli, "c", f"--in={src}", f"--out={tmp_path / 'o.gip'}")
+    assert r.returncode == 1 and "No HIP device" in r.stderr

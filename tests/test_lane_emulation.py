@@ -28,7 +28,7 @@ def emu():
     so = os.path.join(out_dir, "liblane_emulation.so")
     srcs = [os.path.join(HERE, "lane_emulation.cpp"), os.path.join(ROOT, "gpuar_amd", "csrc", "lane_codec.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000", "-DGPUAR_LANE_TEST_PERTURB",
                                "-fconstexpr-loop-limit=1000000", "-I", os.path.join(ROOT, "include"), "-o", so, srcs[0]])
     lib = C.CDLL(so)
     lib.emu_encode_slots.restype = C.c_int

@@ -1,0 +1,71 @@
+"""Multi-GPU path on CPU: world_size-2 `gloo` processes shard one stream by packet
+ranges, each codes its own range, the segments concatenated in rank order must equal
+the single-process stream byte for byte -- and the timing/size reductions bench.py uses
+(MAX over ranks, all_gather of segment sizes) must work.  The codec here is the oracle,
+standing in for the device (this test is about the sharding, not the kernels)."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gpuar_amd import sharding, synth
+
+
+def test_plan_shards_properties():
+    for n in [0, 1, 8191, 8192, 8193, 64 * 8192, 64 * 8192 + 1, 1000003, 1 << 30]:
+        for world in [1, 2, 3, 4, 8]:
+            plan = sharding.plan_shards(n, world)
+            assert len(plan) == world and sum(l for _, l in plan) == n
+            at = 0
+            for off, length in plan:
+                assert off % 8192 == 0 and (length == 0 or off == at)
+                if length:
+                    at = off + length
+            # every shard but the last non-empty one is a whole number of wavefronts of packets
+            nonempty = [(o, l) for o, l in plan if l]
+            for o, l in nonempty[:-1]:
+                assert l % (64 * 8192) == 0
+    assert sharding.weak_shard(8 << 30, 3) == (3 * (8 << 30), 8 << 30)
+
+
+def _worker(rank, world, port, n, kind, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    off, length = sharding.plan_shards(n, world)[rank]
+    shard = synth.generate(kind, seed, length, offset=off)            # generated independently per rank
+    seg = O.PortOracle().encode_stream(shard)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([seg.size], dtype=torch.int64))
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)               # stand-in for the per-rank elapsed time
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, seg.tobytes(), [int(s.item()) for s in sizes], float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,n", [("text", 200 * 8192 + 77), ("uniform", 130 * 8192)])
+def test_two_rank_segments_concatenate_to_the_whole_stream(kind, n):
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, kind, 9, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = O.PortOracle().encode_stream(synth.generate(kind, 9, n))
+    joined = sharding.concat_segments(seg for _, seg, _, _ in got)
+    assert hashlib.md5(joined).hexdigest() == hashlib.md5(whole.tobytes()).hexdigest()
+    assert got[0][2] == got[1][2] == [len(got[0][1]), len(got[1][1])]     # all_gather of segment sizes
+    assert got[0][3] == got[1][3] == 1.5                                  # MAX over ranks
