@@ -202,15 +202,29 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, co
     dec.open(col, pkt, limit, live);
     const uint32_t len_max = wave_max(dec.ulen);
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
-    // whole groups of 4 symbols that every lane decodes: no per-lane predicate,
-    // one dword store and one 32-byte scalar load of reciprocals per group
+    // Whole blocks of 64 symbols that every lane decodes: no per-lane predicate;
+    // the 64 output bytes gather in 16 registers and leave as four back-to-back
+    // 16-byte stores, i.e. one whole 64-byte sector of this lane's output line
+    // at a time (dword-at-a-time stores from 64 lanes at an 8 KiB stride were
+    // measured to cost ~10x the output bytes in HBM writes: every partial
+    // sector left L2 before its neighbours arrived).
     uint32_t i = 0;
-    for (; i + 4u <= len_min; i += 4u) {
-        Recip rc[4];
+    for (; i + 64u <= len_min; i += 64u) {
+        uint32_t block[16];
+#pragma unroll 1
+        for (uint32_t g = 0; g < 16u; ++g) {
+            const uint32_t at = i + 4u * g;                  // wave-uniform
+            Recip rc[4];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[i + j];
+            for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[at + j];
+            uint32_t word = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) dec.step(i + j, rc[j], out);
+            for (uint32_t j = 0; j < 4; ++j) word |= dec.step_symbol(at + j, rc[j]) << (8u * j);
+            block[g] = word;                                 // uniform index: register-indexed move
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+#pragma unroll
+        for (uint32_t v = 0; v < 4; ++v) dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);
     }
     for (; i < len_max; ++i) {              // the ragged rest (the file's last packet, or a partial wavefront)
         const Recip rc = g_recip.r[i];

@@ -816,7 +816,8 @@ struct DecoderLane2 {
         skip(16u);
     }
 
-    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
+    // decodes symbol i and returns it; the caller places it (see put_symbol / flush)
+    GPUAR_LANE uint32_t step_symbol(uint32_t i, Recip rc) {
         const uint32_t total = 256u + i;
         const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
         const uint32_t num = GPUAR_MUL24(((code - lo) & 0xFFFFu) + 1u, total) - 1u;
@@ -835,11 +836,6 @@ struct DecoderLane2 {
         q = q < total ? q : total - 1u;
         uint32_t cum_lo, cum_hi;
         const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
-        outword |= sym << (8u * (i & 3u));
-        if ((i & 3u) == 3u) {
-            store32(out + (i & ~3u), outword);
-            outword = 0;
-        }
         narrow(lo, hi, cum_lo, cum_hi, rc);
         const Renorm r = renorm_split(lo, hi);
         const uint32_t fresh = peek();                         // e + u <= 31 bits are needed
@@ -848,6 +844,17 @@ struct DecoderLane2 {
         code = ((code << r.e) | e_bits) & 0xFFFFu;
         if (r.u) code = (((code << r.u) ^ 0x8000u) | u_bits) & 0xFFFFu;
         skip(r.e + r.u);
+        return sym;
+    }
+
+    // simple placement: one dword store per four symbols
+    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
+        const uint32_t sym = step_symbol(i, rc);
+        outword |= sym << (8u * (i & 3u));
+        if ((i & 3u) == 3u) {
+            store32(out + (i & ~3u), outword);
+            outword = 0;
+        }
     }
 
     GPUAR_LANE void finish(uint8_t *out) {
