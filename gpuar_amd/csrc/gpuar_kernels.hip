@@ -96,6 +96,10 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     __shared__ EncodeLds lds;
 
     const uint32_t lane = threadIdx.x & 63u;
+    // wavefront 0 models, wavefront 1 codes.  The dispatcher was observed
+    // (tools/hwid_probe.hip) to give every SIMD one wavefront 0 and one
+    // wavefront 1 of the four resident workgroups, so each SIMD carries one
+    // modeler and one coder; nothing depends on that placement but speed.
     const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;

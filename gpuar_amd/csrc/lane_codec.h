@@ -23,6 +23,8 @@
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
 #define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
+// (a ^ 1) + b in one instruction; callers use only the low 16 bits
+#define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // quotient ESTIMATE (v_cvt, v_rcp_f32, v_mul, v_cvt): within 1 of floor(num/den)
 // for num < 2^30, den <= 2^16, quotient < 2^14; the callers correct it exactly
 #define GPUAR_RCP_QUOT(num, den) \
@@ -38,6 +40,7 @@
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
+#define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #ifdef GPUAR_LANE_TEST_PERTURB
 // test harness only: the estimate is deliberately off by one both ways on a
 // rotating schedule, so the exact correction that follows it is exercised
@@ -359,48 +362,49 @@ struct InorderModel {
 };
 
 // The modeler as the kernel runs it: same tree, but
-//  * depths 0 and 1 (3 nodes) live in registers, depths 2..7 in LDS rows;
-//  * software-pipelined: while symbol i is being accounted, the six LDS nodes
-//    of symbol i+1 are already being fetched.  Each fetch is issued right
-//    AFTER the store to the same depth for symbol i, and LDS operations of a
-//    wavefront complete in order, so a node shared by both symbols is read
-//    with symbol i's increment already applied.
+//  * the root lives in a register, depths 1..7 in LDS rows;
+//  * software-pipelined: while symbol i is being accounted, the seven LDS
+//    nodes of symbol i+1 are already being fetched.  Each fetch is issued
+//    right AFTER the store to the same depth for symbol i, and LDS operations
+//    of a wavefront complete in order, so a node shared by both symbols is
+//    read with symbol i's increment already applied.  The seven node addresses
+//    travel with the prefetched values, so each is computed once per symbol.
 template <uint32_t kRowShift>
 struct ModelerLane {
     InorderModel<kRowShift> tree;
-    uint32_t root, left_half, right_half;   // depth 0, depth 1 (symbols < 128 / >= 128)
-    uint32_t left[6];                       // depths 2..7 of the NEXT symbol to account
+    uint32_t root;                          // depth 0
+    uint32_t left[7];                       // depths 1..7 of the NEXT symbol to account
+    uint16_t *where[7];                     // ... and where they live
 
     GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
         tree.col = col;
         tree.reset();
         root = 128u;
-        left_half = right_half = 64u;
         const uint32_t xs = first_symbol << kRowShift;
 #pragma unroll
-        for (int k = 2; k < 8; ++k) left[k - 2] = *tree.node(xs, k);
+        for (int k = 1; k < 8; ++k) {
+            where[k - 1] = tree.node(xs, k);
+            left[k - 1] = *where[k - 1];
+        }
     }
 
     // accounts symbol x (model total `total`), prefetches for x_next;
     // returns cumLo | cumHi << 16
     GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
-        const uint32_t xs = x << kRowShift, xn = x_next << kRowShift;
-        const uint32_t z = x * 0x10001u + 0x10000u;      // low half: bits of x, high half: bits of x + 1
-        const uint32_t high = x >> 7;
-        const uint32_t quarter = x >> 6;
-        uint32_t acc = ((z >> 8) & 0x10001u) * total;      // x == 255: cumHi is the whole total
-        acc += root * ((z >> 7) & 0x10001u);
-        acc += (high ? right_half : left_half) * ((z >> 6) & 0x10001u);
-        root += high ^ 1u;
-        left_half += (quarter == 0u) ? 1u : 0u;
-        right_half += (quarter == 2u) ? 1u : 0u;
+        const uint32_t xn = x_next << kRowShift;
+        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
+        uint32_t acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);   // x == 255: cumHi is the whole total
+        const uint32_t pick0 = (z >> 7) & 0x10001u;
+        acc += GPUAR_MUL24(root, pick0);
+        root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
 #pragma unroll
-        for (int k = 2; k < 8; ++k) {
-            const uint32_t pick = (z >> (7 - k)) & 0x10001u;
-            const uint32_t l = left[k - 2];
-            acc += l * pick;
-            *tree.node(xs, k) = static_cast<uint16_t>((pick ^ 1u) + l);
-            left[k - 2] = *tree.node(xn, k);
+        for (int k = 1; k < 8; ++k) {
+            const uint32_t pick = (z >> (7 - k)) & 0x10001u;      // low: x goes right at depth k; high: same for x+1
+            const uint32_t l = left[k - 1];
+            acc += GPUAR_MUL24(l, pick);
+            *where[k - 1] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
+            where[k - 1] = tree.node(xn, k);
+            left[k - 1] = *where[k - 1];
         }
         return acc;
     }
@@ -762,11 +766,7 @@ struct DecoderLane2 {
     // (a well-formed packet decodes the same whatever follows it).
     GPUAR_LANE uint32_t fetch() {
         uint32_t w = 0;
-#ifdef GPUAR_DIAG_NOFETCH      // timing experiment only: wrong data, no stream loads
-        w = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(next)) * 2654435761u;
-#else
         if (next < limit) memcpy(&w, next, 4);
-#endif
         next += 4;
         return w;
     }
