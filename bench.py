@@ -59,6 +59,28 @@ def timed_kernel_ms(fn, reps):
     return [a.elapsed_time(b) for a, b in ev]
 
 
+def load_profiled_traffic(args, n_bytes):
+    """HBM bytes per launch from the newest profiles/*_traffic.json (PMC passes of rocprofv3,
+    tools/prof.sh + tools/traffic_from_prof.py), if one exists for this workload size and stream
+    kind; counters cannot be collected from inside this process, so otherwise traffic is null."""
+    import glob
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files or args.kind != "uniform":
+        return out
+    try:
+        t = json.load(open(files[-1]))
+    except Exception:
+        return out
+    if abs(t.get("input_gib", 0) * GIB - n_bytes) > 1:
+        return out
+    for k in ("encode", "decode"):
+        if k in t:
+            out[k] = t[k]["hbm_bytes_per_launch"]
+    out["source"] = os.path.basename(files[-1]) + ": " + t.get("source", "")
+    return out
+
+
 def cpu_baseline(kind, seed, sample_bytes):
     """Reference codec (oracle/_ref: the reference's own arCompress/arDecompress) or, if that
     build is absent, the C port, timed on ONE host core the way the reference times --host
@@ -178,10 +200,12 @@ def main():
         dom = "decode" if dec_avg >= enc_avg else "encode"
         algo_bytes = n + c_bytes
 
-        def roof(ms):
+        traffic = load_profiled_traffic(args, n)
+
+        def roof(ms, which):
             a = algo_bytes / (ms * 1e-3) / 1e9
             return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
-                    "traffic": None}
+                    "algorithmic_bytes_per_launch": algo_bytes, "traffic": traffic.get(which)}
 
         result = {
             "metric": "encode+decode GB/s (uncompressed bytes through encode then decode, kernels only, data resident in HBM)",
@@ -198,8 +222,9 @@ def main():
             "compression_ratio": (c_total + 20) / total_bytes,
             "roundtrip_equal": all_ok, "md5_sample_match": md5_in == md5_out, "md5_sample": md5_in,
             "oracle_prefix_match": oracle_ok, "device_status": status,
-            "roofline": dict(roof(dec_avg if dom == "decode" else enc_avg), kernel=f"{dom}_kernel"),
-            "roofline_encode": roof(enc_avg), "roofline_decode": roof(dec_avg),
+            "roofline": dict(roof(dec_avg if dom == "decode" else enc_avg, dom), kernel=f"{dom}_kernel"),
+            "roofline_encode": roof(enc_avg, "encode"), "roofline_decode": roof(dec_avg, "decode"),
+            "traffic_source": traffic.get("source"),
         }
 
     # ---- configs[1]: the 64 MiB stand-in for data/random_64m.dat, rank 0 only ----
