@@ -23,6 +23,8 @@
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
 #define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
+// the same where hipcc cannot see the 24-bit bound by itself (it would emit and + v_mul_lo_u32)
+#define GPUAR_MUL24_VV(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // quotient ESTIMATE (v_cvt, v_rcp_f32, v_mul, v_cvt): within 1 of floor(num/den)
@@ -40,6 +42,7 @@
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
+#define GPUAR_MUL24_VV(a, b) ((a) * (b))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #ifdef GPUAR_LANE_TEST_PERTURB
 // test harness only: the estimate is deliberately off by one both ways on a
@@ -152,8 +155,8 @@ struct ModelTree {
 // Interval narrowing (applySymbolRange :256-299); 16-bit state in 32-bit registers.
 GPUAR_LANE void narrow(uint32_t &lo, uint32_t &hi, uint32_t cum_lo, uint32_t cum_hi, Recip rc) {
     const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-    const uint32_t up = div_total(GPUAR_MUL24(cum_hi, range), rc);
-    const uint32_t dn = div_total(GPUAR_MUL24(cum_lo, range), rc);
+    const uint32_t up = div_total(GPUAR_MUL24_VV(cum_hi, range), rc);
+    const uint32_t dn = div_total(GPUAR_MUL24_VV(cum_lo, range), rc);
     hi = (lo + up - 1u) & 0xFFFFu;
     lo = (lo + dn) & 0xFFFFu;
 }
@@ -690,57 +693,58 @@ struct SubtreeModel {
     // `at`.  State: `below` = count of symbols left of the current node's
     // range, `upper` = count of symbols left of its right end; the target is
     // compared against below + left-count directly, so nothing but these two
-    // bounds is carried down.  Updates the three path nodes; returns the
-    // decision bits (first decision = bit 2).
-    GPUAR_LANE uint32_t descend3(uint32_t at, uint32_t target, uint32_t &below, uint32_t &upper) {
+    // bounds is carried down.  Every decision is kept as "went LEFT" because
+    // that is what the node update adds; `nsym` collects the complemented
+    // symbol bits (nsym = 2*nsym + left).
+    GPUAR_LANE void descend3(uint32_t at, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
         uint32_t a = *row(at);
         uint32_t b0 = *row(at + 1u * kRow), b1 = *row(at + 2u * kRow);
         uint32_t c0 = *row(at + 3u * kRow), c1 = *row(at + 4u * kRow);
         uint32_t c2 = *row(at + 5u * kRow), c3 = *row(at + 6u * kRow);
         GPUAR_PIN7(a, b0, b1, c0, c1, c2, c3);        // all seven in flight together: one LDS round trip
         const uint32_t sa = below + a;
-        const bool ra = target >= sa;
-        below = ra ? sa : below;
-        upper = ra ? upper : sa;
-        const uint32_t b = ra ? b1 : b0;
-        const uint32_t cl = ra ? c2 : c0, ch = ra ? c3 : c1;
+        const bool la = target < sa;
+        below = la ? below : sa;
+        upper = la ? sa : upper;
+        const uint32_t b = la ? b0 : b1;
+        const uint32_t cl = la ? c0 : c2, ch = la ? c1 : c3;
         const uint32_t sb = below + b;
-        const bool rb = target >= sb;
-        below = rb ? sb : below;
-        upper = rb ? upper : sb;
-        const uint32_t c = rb ? ch : cl;
+        const bool lb = target < sb;
+        below = lb ? below : sb;
+        upper = lb ? sb : upper;
+        const uint32_t c = lb ? cl : ch;
         const uint32_t sc = below + c;
-        const bool rc = target >= sc;
-        below = rc ? sc : below;
-        upper = rc ? upper : sc;
-        const uint32_t ia = ra ? 1u : 0u, ib = rb ? 1u : 0u, ic = rc ? 1u : 0u;
-        *row(at) = static_cast<uint16_t>(a + 1u - ia);
-        *row(at + ((1u + ia) << kRowShift)) = static_cast<uint16_t>(b + 1u - ib);
-        *row(at + ((3u + 2u * ia + ib) << kRowShift)) = static_cast<uint16_t>(c + 1u - ic);
-        return (ia << 2) | (ib << 1) | ic;
+        const bool lc = target < sc;
+        below = lc ? below : sc;
+        upper = lc ? sc : upper;
+        *row(at) = static_cast<uint16_t>(a + (la ? 1u : 0u));
+        *row(at + (la ? 1u * kRow : 2u * kRow)) = static_cast<uint16_t>(b + (lb ? 1u : 0u));
+        *row(at + (la ? 3u * kRow : 5u * kRow) + (lb ? 0u : kRow)) = static_cast<uint16_t>(c + (lc ? 1u : 0u));
+        nsym = nsym + nsym + (la ? 1u : 0u);
+        nsym = nsym + nsym + (lb ? 1u : 0u);
+        nsym = nsym + nsym + (lc ? 1u : 0u);
     }
 
-    // the symbol s with cum(s) <= target < cum(s+1); cum_lo = cum(s), cum_hi = cum(s+1)
+    // the symbol s with cum(s) <= target < cum(s+1); cum_lo = cum(s), cum_hi = cum(s+1).
+    // Memory-safe for any target (a target >= total simply walks right).
     GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
-        uint32_t below = 0, upper = total;
-        const bool r0 = target >= root;
-        below = r0 ? root : 0u;
-        upper = r0 ? total : root;
-        const uint32_t h = r0 ? half1 : half0;
+        const bool l0 = target < root;
+        uint32_t below = l0 ? 0u : root;
+        uint32_t upper = l0 ? root : total;
+        const uint32_t h = l0 ? half0 : half1;
         const uint32_t s1 = below + h;
-        const bool r1 = target >= s1;
-        below = r1 ? s1 : below;
-        upper = r1 ? upper : s1;
-        root += r0 ? 0u : 1u;
-        half0 += (!r0 && !r1) ? 1u : 0u;
-        half1 += (r0 && !r1) ? 1u : 0u;
-        const uint32_t top2 = (r0 ? 2u : 0u) | (r1 ? 1u : 0u);
-        const uint32_t mid = descend3((top2 * 7u) << kRowShift, target, below, upper);
-        const uint32_t top5 = (top2 << 3) | mid;
-        const uint32_t low = descend3((28u + top5 * 7u) << kRowShift, target, below, upper);
+        const bool l1 = target < s1;
+        below = l1 ? below : s1;
+        upper = l1 ? s1 : upper;
+        root += l0 ? 1u : 0u;
+        half0 += (l0 && l1) ? 1u : 0u;
+        half1 += (!l0 && l1) ? 1u : 0u;
+        uint32_t nsym = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented bits, MSB first
+        descend3(((nsym ^ 3u) * 7u) << kRowShift, target, below, upper, nsym);
+        descend3((28u + (nsym ^ 31u) * 7u) << kRowShift, target, below, upper, nsym);
         cum_lo = below;
         cum_hi = upper;
-        return (top5 << 3) | low;
+        return nsym ^ 255u;
     }
 };
 
@@ -822,7 +826,7 @@ struct DecoderLane2 {
         const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
         const uint32_t num = GPUAR_MUL24(((code - lo) & 0xFFFFu) + 1u, total) - 1u;
         uint32_t q = GPUAR_RCP_QUOT(num, range);
-        int32_t rem = static_cast<int32_t>(num - GPUAR_MUL24(q & 0xFFFFFFu, range));
+        int32_t rem = static_cast<int32_t>(num - GPUAR_MUL24_VV(q, range));
         if (rem < 0) {
             --q;
             rem += static_cast<int32_t>(range);
@@ -833,17 +837,18 @@ struct DecoderLane2 {
         // keep going on a clamped target -- the walk stays inside the tree and
         // the output inside its 8192 bytes whatever the bits are.
         bad = bad || q >= total;
-        q = q < total ? q : total - 1u;
         uint32_t cum_lo, cum_hi;
         const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
         narrow(lo, hi, cum_lo, cum_hi, rc);
         const Renorm r = renorm_split(lo, hi);
-        const uint32_t fresh = peek();                         // e + u <= 31 bits are needed
-        const uint32_t e_bits = r.e ? fresh >> (32u - r.e) : 0u;
-        const uint32_t u_bits = r.u ? (fresh << r.e) >> (32u - r.u) : 0u;
-        code = ((code << r.e) | e_bits) & 0xFFFFu;
-        if (r.u) code = (((code << r.u) ^ 0x8000u) | u_bits) & 0xFFFFu;
-        skip(r.e + r.u);
+        // e agree-shifts and u underflow-shifts pull e + u (<= 31) fresh bits in
+        // below the old code; every underflow shift is `code ^= 0x4000` then a
+        // shift (:805-818), which over u >= 1 shifts amounts to complementing
+        // the final MSB once
+        const uint32_t n = r.e + r.u;
+        const uint32_t fresh = (peek() >> 1) >> (31u - n);
+        code = (((code << n) | fresh) ^ (r.u ? 0x8000u : 0u)) & 0xFFFFu;
+        skip(n);
         return sym;
     }
 
