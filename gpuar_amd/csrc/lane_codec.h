@@ -23,6 +23,8 @@
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
 #define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
+// bit-field mask ((1 << w) - 1) << off, w and off taken mod 32: one instruction
+#define GPUAR_BFM(w, off) ([](uint32_t w_, uint32_t o_) { uint32_t r_; asm("v_bfm_b32 %0, %1, %2" : "=v"(r_) : "v"(w_), "v"(o_)); return r_; }((w), (off)))
 // the same where hipcc cannot see the 24-bit bound by itself (it would emit and + v_mul_lo_u32)
 #define GPUAR_MUL24_VV(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
@@ -43,6 +45,7 @@
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
+#define GPUAR_BFM(w, off) (((1u << ((w) & 31u)) - 1u) << ((off) & 31u))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #ifdef GPUAR_LANE_TEST_PERTURB
 // test harness only: the estimate is deliberately off by one both ways on a
@@ -437,25 +440,21 @@ struct CoderLane {
     }
 
     // append `count` (<= 32) bits, MSB first.  Straight-line except for the
-    // one predicated store: both outcomes are computed and selected.  A packet
-    // that outgrows its slot keeps overwriting the slot's last dword (never
-    // beyond it); finish() sees pos > limit and reports the overflow.
+    // one predicated region around the store.  A packet that outgrows its slot
+    // keeps overwriting the slot's last dword (never beyond it); finish() sees
+    // pos > limit and reports the overflow.
     GPUAR_LANE void put(uint32_t bits, uint32_t count) {
         const uint32_t total = n + count;                       // <= 63
         const uint32_t left_aligned = bits << ((32u - count) & 31u);
         // the oldest 32 bits of acc:bits (a funnel shift; n < 32)
         const uint32_t word = static_cast<uint32_t>(((static_cast<uint64_t>(acc) << 32) | left_aligned) >> n);
-        const bool flush = total >= 32u;
-        if (flush) {
-            const uint32_t be = bswap32(word);
+        acc = (acc << (count & 31u)) | bits;                    // right if nothing leaves
+        if (total >= 32u) {
             const uint32_t at = pos < kSlot - kHdr - 4u ? pos : kSlot - kHdr - 4u;
-            memcpy(base + (body_off + at), &be, 4);
+            store32(base + (body_off + at), bswap32(word));
+            pos += 4u;
+            acc = bits & GPUAR_BFM(total, 0u);                  // the total-32 youngest bits stay, all from `bits`
         }
-        // after a flush the total-32 youngest bits stay, all of them from `bits`
-        const uint32_t kept = bits & ((1u << (total & 31u)) - 1u);
-        const uint32_t grown = (acc << (count & 31u)) | bits;
-        acc = flush ? kept : grown;
-        pos += flush ? 4u : 0u;
         n = total & 31u;
     }
 
@@ -493,16 +492,23 @@ struct CoderLane {
         p = ((a1 << u) & 0x7FFFu) | (((b1 << u) & 0x7FFFu) << 16);
         // the e agreed bits (same in lo and hi): top, then `pending` copies of
         // !top, then the rest.  Branch-free for the usual pending <= 16.
+        // The e agreed bits (same in lo and hi) leave as: their MSB, then `pending`
+        // copies of its complement, then the rest.  Inserting p complement bits
+        // behind the MSB of an e-bit number A is the number A + (2^p - 1) * 2^(e-1)
+        // (MSB 1: the carry pushes it up p places; MSB 0: p ones appear below
+        // it), so the usual case pending <= 16 is one add of a bit-field mask.
         const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
-        const uint32_t em1 = (e - 1u) & 31u;
-        const uint32_t top = (agreed >> em1) & 1u;
-        const uint32_t rest = agreed & ((1u << em1) - 1u);
+        const uint32_t em1 = e - 1u;
         const bool shift_out = e != 0u;
         const bool long_run = shift_out && pending > 16u;     // rare: more than 16 underflow bits owed
-        if (long_run) put_bit_then_run(top, pending);
-        const uint32_t fill = (1u << (pending & 31u)) - 1u + top;
-        const uint32_t bits = long_run ? rest : ((fill << em1) | rest);
-        const uint32_t count = long_run ? em1 : e + pending;
+        uint32_t bits = agreed + GPUAR_BFM(pending, em1);
+        uint32_t count = e + pending;
+        if (long_run) {
+            const uint32_t top = (agreed >> (em1 & 31u)) & 1u;
+            put_bit_then_run(top, pending);
+            bits = agreed & GPUAR_BFM(em1, 0u);
+            count = em1;
+        }
         put(shift_out ? bits : 0u, shift_out ? count : 0u);
         pending = (shift_out ? 0u : pending) + u;
     }
