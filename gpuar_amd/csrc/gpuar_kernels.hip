@@ -200,9 +200,10 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 // Decode: replaces garDecompress + arDecompress (:916-934, 848-892)
 // ---------------------------------------------------------------------------
+constexpr uint32_t kDecodeRecords = 36;
 __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, const uint8_t *limit,
                                             uint8_t *out, bool live) {
-    DecoderLane2<7> dec;
+    DecoderLane2<10> dec;
     dec.open(col, pkt, limit, live);
     const uint32_t len_max = wave_max(dec.ulen);
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
@@ -242,12 +243,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, co
 
 __global__ void __launch_bounds__(kLanes)
 decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint8_t tree[kTreeRows * kLanes * 2];   // 32 KiB: 252 rows x (64 lanes x u16), subtree layout
+    __shared__ uint4 tree[kDecodeRecords * kLanes];    // 36 KiB: 36 records x 64 lanes x 16 B
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const uint8_t *pkt = slots + (live ? packet : 0) * static_cast<size_t>(kSlot);
-    decode_wave(tree + 2u * lane_column(lane), pkt, pkt + kSlot, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), pkt, pkt + kSlot, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
 // Decode from a back-to-back packet stream (the bytes after the 20-byte .gip
@@ -255,13 +256,13 @@ decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8
 __global__ void __launch_bounds__(kLanes)
 decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offsets,
                      uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint8_t tree[kTreeRows * kLanes * 2];
+    __shared__ uint4 tree[kDecodeRecords * kLanes];
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const uint8_t *pkt = stream + (live ? offsets[packet] : 0);
     const uint8_t *limit = stream + offsets[n_packets];
-    decode_wave(tree + 2u * lane_column(lane), pkt, limit, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), pkt, limit, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
 // ---------------------------------------------------------------------------

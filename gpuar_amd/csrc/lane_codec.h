@@ -187,6 +187,37 @@ GPUAR_LANE Renorm renorm_split(uint32_t &lo, uint32_t &hi) {
 
 GPUAR_LANE uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
+// typed accesses to addresses that are suitably aligned by construction
+struct Quad {
+    uint32_t w[4];
+};
+GPUAR_LANE Quad load128(const uint8_t *at) {
+    Quad q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4 *>(at);
+    q.w[0] = v.x, q.w[1] = v.y, q.w[2] = v.z, q.w[3] = v.w;
+#else
+    memcpy(q.w, at, 16);
+#endif
+    return q;
+}
+GPUAR_LANE void store128(uint8_t *at, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint4 *>(at) = make_uint4(a, b, c, d);
+#else
+    const uint32_t w[4] = {a, b, c, d};
+    memcpy(at, w, 16);
+#endif
+}
+GPUAR_LANE void store16(uint8_t *at, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint16_t *>(at) = static_cast<uint16_t>(v);
+#else
+    const uint16_t h = static_cast<uint16_t>(v);
+    memcpy(at, &h, 2);
+#endif
+}
+
 // 32-bit store to an address that is 4-byte aligned by construction
 GPUAR_LANE void store32(uint8_t *at, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -665,49 +696,53 @@ struct DecoderLane {
 
 // ===========================================================================
 // Decoder, second form: the symbol search touches LDS in two round trips
-// instead of eight.  Depths 0 and 1 of the left-count tree live in registers;
-// depths 2..4 and 5..7 are stored as 3-level subtrees of 7 consecutive rows
-// [a | b0 b1 | c0 c1 c2 c3], so one address plus seven immediate offsets
-// fetches everything the next three decisions can need, and those decisions
-// are then taken in registers.  Same counts, same sums, same symbols as
-// ModelTree::decode_step.
-//   rows  0..27   : 4 subtrees rooted at the depth-2 nodes (index = top 2 bits)
-//   rows 28..251  : 32 subtrees rooted at the depth-5 nodes (index = top 5 bits)
+// instead of eight, with one 16-byte read each.  Depths 0 and 1 of the
+// left-count tree live in registers; depths 2..4 and 5..7 are stored as
+// 3-level subtrees, each one 16-byte RECORD of eight u16
+//     [a | b0 b1 | c0 c1 c2 c3 | pad]
+// so a single ds_read_b128 fetches everything the next three decisions can
+// need, and those decisions are then taken in registers.  (Measured with
+// tools/lds_probe.hip: at these occupancies a u16 LDS read costs the CU about
+// as much as a 16-byte one, and the seven separate u16 reads per subtree were
+// what bounded the previous form of this kernel.)  Same counts, same sums,
+// same symbols as ModelTree::decode_step.
+//   records  0..3   : subtrees rooted at the depth-2 nodes (index = top 2 bits)
+//   records  4..35  : subtrees rooted at the depth-5 nodes (index = top 5 bits)
+// kRecShift = log2(bytes between consecutive records of one lane): 10 on the
+// GPU (64 lanes x 16 B, lane-minor: any 16 lanes of a ds_read_b128 group cover
+// all 64 banks whatever records they address), 4 on the host.
 // ===========================================================================
-template <uint32_t kRowShift>
+template <uint32_t kRecShift>
 struct SubtreeModel {
-    uint8_t *col;                       // this lane's column; row r at col + (r << kRowShift)
+    uint8_t *col;                       // this lane's 16-byte column
     uint32_t root, half0, half1;        // depth 0; depth 1 under root's left / right child
 
-    static constexpr uint32_t kRow = 1u << kRowShift;
-
-    GPUAR_LANE uint16_t *row(uint32_t byte_off) const { return reinterpret_cast<uint16_t *>(col + byte_off); }
+    static constexpr uint32_t kRecords = 36;
 
     GPUAR_LANE void reset() {
         root = 128u;
         half0 = half1 = 64u;
 #pragma unroll 1
-        for (uint32_t r = 0; r < 252u; ++r) {
-            const uint32_t within = r < 28u ? r % 7u : (r - 28u) % 7u;       // 0 | 1,2 | 3..6
-            const uint32_t depth_in = within == 0u ? 0u : (within < 3u ? 1u : 2u);
-            const uint32_t top = r < 28u ? 32u : 4u;                          // depth 2 / depth 5 value
-            *row(r << kRowShift) = static_cast<uint16_t>(top >> depth_in);
+        for (uint32_t r = 0; r < kRecords; ++r) {
+            const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
+            const uint32_t ab = top | ((top >> 1) << 16);          // a, b0
+            const uint32_t bc = (top >> 1) | ((top >> 2) << 16);   // b1, c0
+            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // c1, c2 ; c3, pad
+            store128(col + (r << kRecShift), ab, bc, cc, cc);
         }
     }
 
-    // Three decisions inside the subtree whose first row is at byte offset
-    // `at`.  State: `below` = count of symbols left of the current node's
-    // range, `upper` = count of symbols left of its right end; the target is
-    // compared against below + left-count directly, so nothing but these two
-    // bounds is carried down.  Every decision is kept as "went LEFT" because
-    // that is what the node update adds; `nsym` collects the complemented
-    // symbol bits (nsym = 2*nsym + left).
-    GPUAR_LANE void descend3(uint32_t at, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
-        uint32_t a = *row(at);
-        uint32_t b0 = *row(at + 1u * kRow), b1 = *row(at + 2u * kRow);
-        uint32_t c0 = *row(at + 3u * kRow), c1 = *row(at + 4u * kRow);
-        uint32_t c2 = *row(at + 5u * kRow), c3 = *row(at + 6u * kRow);
-        GPUAR_PIN7(a, b0, b1, c0, c1, c2, c3);        // all seven in flight together: one LDS round trip
+    // Three decisions inside record `r`.  State: `below` = count of symbols left
+    // of the current node's range, `upper` = count of symbols left of its right
+    // end; the target is compared against below + left-count directly.  Every
+    // decision is kept as "went LEFT" because that is what the node update
+    // adds; `nsym` collects the complemented symbol bits.
+    GPUAR_LANE void descend3(uint32_t r, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
+        uint8_t *rec = col + (r << kRecShift);
+        const Quad q = load128(rec);                          // one ds_read_b128
+        const uint32_t *w = q.w;
+        const uint32_t a = w[0] & 0xFFFFu, b0 = w[0] >> 16, b1 = w[1] & 0xFFFFu, c0 = w[1] >> 16;
+        const uint32_t c1 = w[2] & 0xFFFFu, c2 = w[2] >> 16, c3 = w[3] & 0xFFFFu;
         const uint32_t sa = below + a;
         const bool la = target < sa;
         below = la ? below : sa;
@@ -723,9 +758,10 @@ struct SubtreeModel {
         const bool lc = target < sc;
         below = lc ? below : sc;
         upper = lc ? sc : upper;
-        *row(at) = static_cast<uint16_t>(a + (la ? 1u : 0u));
-        *row(at + (la ? 1u * kRow : 2u * kRow)) = static_cast<uint16_t>(b + (lb ? 1u : 0u));
-        *row(at + (la ? 3u * kRow : 5u * kRow) + (lb ? 0u : kRow)) = static_cast<uint16_t>(c + (lc ? 1u : 0u));
+        // fields: a = 0, b0 = 1, b1 = 2, c0..c3 = 3..6 (2 bytes each)
+        store16(rec, a + (la ? 1u : 0u));
+        store16(rec + (la ? 2u : 4u), b + (lb ? 1u : 0u));
+        store16(rec + (la ? 6u : 10u) + (lb ? 0u : 2u), c + (lc ? 1u : 0u));
         nsym = nsym + nsym + (la ? 1u : 0u);
         nsym = nsym + nsym + (lb ? 1u : 0u);
         nsym = nsym + nsym + (lc ? 1u : 0u);
@@ -746,8 +782,8 @@ struct SubtreeModel {
         half0 += (l0 && l1) ? 1u : 0u;
         half1 += (!l0 && l1) ? 1u : 0u;
         uint32_t nsym = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented bits, MSB first
-        descend3(((nsym ^ 3u) * 7u) << kRowShift, target, below, upper, nsym);
-        descend3((28u + (nsym ^ 31u) * 7u) << kRowShift, target, below, upper, nsym);
+        descend3(nsym ^ 3u, target, below, upper, nsym);
+        descend3(4u + (nsym ^ 31u), target, below, upper, nsym);
         cum_lo = below;
         cum_hi = upper;
         return nsym ^ 255u;

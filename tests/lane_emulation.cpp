@@ -82,10 +82,10 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
 int emu_decode_stream2(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)
 {
     int bad = 0;
-    std::vector<uint16_t> tree(256);
+    std::vector<uint16_t> tree(36 * 8);
     const uint8_t *limit = stream + pkt_offsets[np];
     for (size_t p = 0; p < np; ++p) {
-        DecoderLane2<1> dec;
+        DecoderLane2<4> dec;
         uint8_t *o = out + p * kPacket;
         dec.open(reinterpret_cast<uint8_t *>(tree.data()), stream + pkt_offsets[p], limit, true);
         for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
