@@ -37,6 +37,8 @@
 // into the branches that consume them (which would serialise the round trips)
 #define GPUAR_PIN7(a, b, c, d, e, f, g) \
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g))
+// the load that produces q is issued here, before any later store (no wait is implied)
+#define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
 #define GPUAR_PIN_ORDER(x) asm volatile("" : "+v"(x) : : "memory")
 #else
@@ -57,6 +59,7 @@
 #endif
 #define GPUAR_PIN7(a, b, c, d, e, f, g) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
+#define GPUAR_PIN_LOAD(q) ((void)0)
 #endif
 
 namespace gpuar {
@@ -714,14 +717,29 @@ struct DecoderLane {
 // ===========================================================================
 template <uint32_t kRecShift>
 struct SubtreeModel {
+    // What three decisions inside one record leave to be written back.
+    struct Path {
+        uint8_t *rec;
+        uint32_t a, b, c;          // the three nodes on the path, already incremented where the walk went left
+        uint32_t off_b, off_c;     // byte offsets of b and c inside the record
+    };
+
     uint8_t *col;                       // this lane's 16-byte column
     uint32_t root, half0, half1;        // depth 0; depth 1 under root's left / right child
+    Path owed;                          // write-back of the previous symbol's low record, not yet issued
 
     static constexpr uint32_t kRecords = 36;
 
     GPUAR_LANE void reset() {
         root = 128u;
         half0 = half1 = 64u;
+        // nothing owed yet: a write-back that rewrites record 35 with its initial values
+        owed.rec = col + ((kRecords - 1u) << kRecShift);
+        owed.a = 4u;
+        owed.b = 2u;
+        owed.c = 1u;
+        owed.off_b = 2u;
+        owed.off_c = 6u;
 #pragma unroll 1
         for (uint32_t r = 0; r < kRecords; ++r) {
             const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
@@ -732,14 +750,12 @@ struct SubtreeModel {
         }
     }
 
-    // Three decisions inside record `r`.  State: `below` = count of symbols left
-    // of the current node's range, `upper` = count of symbols left of its right
-    // end; the target is compared against below + left-count directly.  Every
-    // decision is kept as "went LEFT" because that is what the node update
-    // adds; `nsym` collects the complemented symbol bits.
-    GPUAR_LANE void descend3(uint32_t r, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
-        uint8_t *rec = col + (r << kRecShift);
-        const Quad q = load128(rec);                          // one ds_read_b128
+    // Three decisions inside the record whose 16 bytes are `q`.  State: `below`
+    // = count of symbols left of the current node's range, `upper` = count of
+    // symbols left of its right end; the target is compared against below +
+    // left-count directly.  Every decision is kept as "went LEFT" because that
+    // is what the node update adds; `nsym` collects the complemented symbol bits.
+    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
         const uint32_t *w = q.w;
         const uint32_t a = w[0] & 0xFFFFu, b0 = w[0] >> 16, b1 = w[1] & 0xFFFFu, c0 = w[1] >> 16;
         const uint32_t c1 = w[2] & 0xFFFFu, c2 = w[2] >> 16, c3 = w[3] & 0xFFFFu;
@@ -758,17 +774,33 @@ struct SubtreeModel {
         const bool lc = target < sc;
         below = lc ? below : sc;
         upper = lc ? sc : upper;
-        // fields: a = 0, b0 = 1, b1 = 2, c0..c3 = 3..6 (2 bytes each)
-        store16(rec, a + (la ? 1u : 0u));
-        store16(rec + (la ? 2u : 4u), b + (lb ? 1u : 0u));
-        store16(rec + (la ? 6u : 10u) + (lb ? 0u : 2u), c + (lc ? 1u : 0u));
         nsym = nsym + nsym + (la ? 1u : 0u);
         nsym = nsym + nsym + (lb ? 1u : 0u);
         nsym = nsym + nsym + (lc ? 1u : 0u);
+        // fields: a = 0, b0 = 1, b1 = 2, c0..c3 = 3..6 (2 bytes each)
+        Path p;
+        p.rec = rec;
+        p.a = a + (la ? 1u : 0u);
+        p.b = b + (lb ? 1u : 0u);
+        p.c = c + (lc ? 1u : 0u);
+        p.off_b = la ? 2u : 4u;
+        p.off_c = (la ? 6u : 10u) + (lb ? 0u : 2u);
+        return p;
+    }
+    GPUAR_LANE void write_back(const Path &p) {
+        store16(p.rec, p.a);
+        store16(p.rec + p.off_b, p.b);
+        store16(p.rec + p.off_c, p.c);
     }
 
     // the symbol s with cum(s) <= target < cum(s+1); cum_lo = cum(s), cum_hi = cum(s+1).
     // Memory-safe for any target (a target >= total simply walks right).
+    // Order of LDS traffic (LDS operations of a wavefront complete in order):
+    //   read mid record -> write back the PREVIOUS symbol's low record (mid and
+    //   low records are disjoint; a later read of the same low record comes
+    //   after this write) -> read low record -> write back the mid record ->
+    //   (low record's write-back is owed to the next call / flush()).
+    // Each write-back thus sits in the shadow of a read instead of in front of it.
     GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
         const bool l0 = target < root;
         uint32_t below = l0 ? 0u : root;
@@ -778,16 +810,27 @@ struct SubtreeModel {
         const bool l1 = target < s1;
         below = l1 ? below : s1;
         upper = l1 ? s1 : upper;
-        root += l0 ? 1u : 0u;
+        uint32_t nsym = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented bits, MSB first
+        uint8_t *rec_mid = col + ((nsym ^ 3u) << kRecShift);
+        Quad q_mid = load128(rec_mid);                        // ds_read_b128 #1 ...
+        GPUAR_PIN_LOAD(q_mid);
+        write_back(owed);                                     // ... with the previous symbol's write-back behind it
+        root += l0 ? 1u : 0u;                                 // register nodes: also in the shadow of read #1
         half0 += (l0 && l1) ? 1u : 0u;
         half1 += (!l0 && l1) ? 1u : 0u;
-        uint32_t nsym = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented bits, MSB first
-        descend3(nsym ^ 3u, target, below, upper, nsym);
-        descend3(4u + (nsym ^ 31u), target, below, upper, nsym);
+        const Path p_mid = decide3(rec_mid, q_mid, target, below, upper, nsym);
+        uint8_t *rec_low = col + ((4u + (nsym ^ 31u)) << kRecShift);
+        Quad q_low = load128(rec_low);                        // ds_read_b128 #2 ...
+        GPUAR_PIN_LOAD(q_low);
+        write_back(p_mid);                                    // ... with the first write-back behind it
+        owed = decide3(rec_low, q_low, target, below, upper, nsym);
         cum_lo = below;
         cum_hi = upper;
         return nsym ^ 255u;
     }
+
+    // issue the write-back still owed (call once after the last symbol; harmless if repeated)
+    GPUAR_LANE void flush() { write_back(owed); }
 };
 
 // Decoder lane built on SubtreeModel, with a leaner bit reader: two aligned
@@ -905,6 +948,7 @@ struct DecoderLane2 {
     }
 
     GPUAR_LANE void finish(uint8_t *out) {
+        model.flush();
         for (uint32_t b = ulen & ~3u; b < ulen; ++b) out[b] = static_cast<uint8_t>(outword >> (8u * (b & 3u)));
     }
 };
