@@ -1,30 +1,24 @@
 // gpuar_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the GPUAR packet codec.
 //
-// One lane = one packet, 64 packets per wavefront, one wavefront per
-// workgroup.  What the reference does with a 32-thread CUDA block, a 516-byte
-// Fenwick tree per thread in shared memory and bit-at-a-time loops
+// One lane = one packet, 64 packets per wavefront.  What the reference does
+// with one CUDA thread per packet in 32-thread blocks, a 516-byte Fenwick tree
+// per thread in shared memory and bit-at-a-time loops
 // (/root/reference/src/gpuar_kernel.cu:894-934, 205-238, 321-367, 787-836) is
-// re-derived here for a 64-wide wavefront:
+// re-derived here for 64-wide wavefronts (per-lane code: lane_codec.h):
 //
-//  * Model: per lane a complete binary "left-count" tree over the 256
-//    symbols (255 u16 nodes, heap order) in LDS, laid out node-major /
-//    lane-minor so that whatever symbol each lane touches, lane l always hits
-//    LDS bank (l & 31) -- no bank conflicts by construction.  One root-to-leaf
-//    walk (8 reads + 8 writes, addresses known from the symbol alone) yields
-//    cumLo, cumHi AND performs the count update; the decoder's symbol search
-//    is the same walk steered by the code value.  Bit-exact with the
-//    reference's Fenwick model because both are exact integer prefix sums of
-//    the same counts.
-//  * Range update: the divisor `total = 256 + i` is wave-uniform, so the two
-//    divisions per symbol become mul-hi by a reciprocal read with scalar
-//    loads from a compile-time table (exact for every numerator < 2^30).
-//  * Renormalisation in closed form (count-leading-zeros instead of the
-//    reference's data-dependent loop): e matching bits, then u underflow
-//    bits, never interleaved (proof sketch at renorm_split()).
-//  * Bits leave through a per-lane 64-bit accumulator, one big-endian dword
-//    store per 32 bits.
+//  * encode_kernel: two wavefronts per 64 packets -- a MODELER (adaptive
+//    models in LDS: per lane a binary left-count tree, node-major/lane-minor
+//    so lane l always hits bank l & 31; software-pipelined walk that yields
+//    cumLo, cumHi and the count update) and a CODER (interval narrowing by a
+//    wave-uniform reciprocal, closed-form renormalisation, bit sink), joined
+//    by an LDS ring;
+//  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
+//    two 16-byte subtree records per symbol instead of walking eight levels;
+//  * compaction (scan + gather) and synthetic-stream generators.
 //
-// No MFMA: this is integer, bit-serial work.
+// Bit-exact with the reference: same counts, same integer arithmetic, same
+// bitstream.  No MFMA: this is integer, bit-serial
+// work bounded by VALU issue and LDS operations, not by HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
