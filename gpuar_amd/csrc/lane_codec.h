@@ -402,29 +402,32 @@ struct InorderModel {
 };
 
 // The modeler as the kernel runs it: same tree, but
-//  * the root lives in a register, depths 1..7 in LDS rows;
-//  * software-pipelined: while symbol i is being accounted, the seven LDS
+//  * depths 0 and 1 (three nodes) live in registers, depths 2..7 in LDS rows
+//    (an LDS operation costs the CU more than the few selects that replace it);
+//  * software-pipelined: while symbol i is being accounted, the six LDS
 //    nodes of symbol i+1 are already being fetched.  Each fetch is issued
 //    right AFTER the store to the same depth for symbol i, and LDS operations
 //    of a wavefront complete in order, so a node shared by both symbols is
-//    read with symbol i's increment already applied.  The seven node addresses
+//    read with symbol i's increment already applied.  The six node addresses
 //    travel with the prefetched values, so each is computed once per symbol.
 template <uint32_t kRowShift>
 struct ModelerLane {
     InorderModel<kRowShift> tree;
     uint32_t root;                          // depth 0
-    uint32_t left[7];                       // depths 1..7 of the NEXT symbol to account
-    uint16_t *where[7];                     // ... and where they live
+    uint32_t half0, half1;                  // depth 1: under the root's left / right child
+    uint32_t left[6];                       // depths 2..7 of the NEXT symbol to account
+    uint16_t *where[6];                     // ... and where they live
 
     GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
         tree.col = col;
         tree.reset();
         root = 128u;
+        half0 = half1 = 64u;
         const uint32_t xs = first_symbol << kRowShift;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            where[k - 1] = tree.node(xs, k);
-            left[k - 1] = *where[k - 1];
+        for (int k = 2; k < 8; ++k) {
+            where[k - 2] = tree.node(xs, k);
+            left[k - 2] = *where[k - 2];
         }
     }
 
@@ -437,14 +440,21 @@ struct ModelerLane {
         const uint32_t pick0 = (z >> 7) & 0x10001u;
         acc += GPUAR_MUL24(root, pick0);
         root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
+        // depth 1 in registers: two LDS operations fewer per symbol
+        const bool upper_half = x >= 128u;
+        const uint32_t pick1 = (z >> 6) & 0x10001u;
+        acc += GPUAR_MUL24(upper_half ? half1 : half0, pick1);
+        const uint32_t quarter = x >> 6;
+        half0 += quarter == 0u ? 1u : 0u;
+        half1 += quarter == 2u ? 1u : 0u;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
+        for (int k = 2; k < 8; ++k) {
             const uint32_t pick = (z >> (7 - k)) & 0x10001u;      // low: x goes right at depth k; high: same for x+1
-            const uint32_t l = left[k - 1];
+            const uint32_t l = left[k - 2];
             acc += GPUAR_MUL24(l, pick);
-            *where[k - 1] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
-            where[k - 1] = tree.node(xn, k);
-            left[k - 1] = *where[k - 1];
+            *where[k - 2] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
+            where[k - 2] = tree.node(xn, k);
+            left[k - 2] = *where[k - 2];
         }
         return acc;
     }
