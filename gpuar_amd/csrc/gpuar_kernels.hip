@@ -49,51 +49,95 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-__device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) {
-    if (avail >= 16) return *reinterpret_cast<const uint4 *>(p);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (size_t b = 0; b < avail; ++b) w[b >> 2] |= static_cast<uint32_t>(p[b]) << (8u * (b & 3u));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
 // ---------------------------------------------------------------------------
 // Encode: replaces garCompress + arCompress (src/gpuar_kernel.cu:894-914, 487-531)
 //
-// Workgroup = 2 wavefronts serving the same 64 packets (lane l <-> packet
-// 64*block + l in both):
-//   wave 0, the MODELER, owns the 64 adaptive models (32 KiB of LDS), reads
-//           the input bytes and turns each symbol into cumLo | cumHi << 16;
-//   wave 1, the CODER, owns the interval state and the bit sink, and turns
-//           those words into the packet bitstream.
-// They meet in a two-half LDS ring of kPhase symbols per half: the modeler
-// fills half (k & 1) while the coder drains the other, one s_barrier per
-// phase.  Why: a packet's model pins 512 B of LDS, so a CU can hold at most
-// 4-5 x 64 packets; splitting the per-symbol work over two wavefronts puts two
-// wavefronts on every SIMD for the same LDS, which is what this
-// latency-/issue-bound integer chain needs.  40 KiB of LDS per workgroup ->
-// exactly 4 workgroups (8 wavefronts) per CU.
+// Workgroup = 3 wavefronts serving the same 64 packets (lane l <-> packet
+// 64*block + l in all three):
+//   wave 0, TOP MODELER: depths 0..4 of the 64 adaptive models (0-1 in
+//           registers, 2-4 in LDS), reads the input bytes, emits its part of
+//           cumLo | cumHi << 16 per symbol;
+//   wave 1, LOW MODELER: depths 5..7 (LDS) and the x == 255 term, same input,
+//           emits the other part;
+//   wave 2, CODER: adds the two parts, owns the interval state and the bit
+//           sink, turns them into the packet bitstream.
+// They meet in a two-half LDS ring of kPhase symbols per half: the modelers
+// fill half (k & 1) while the coder drains the other, one s_barrier per phase.
+//
+// Why three: a packet's model pins 510 B of LDS, so a CU holds only 4 x 64
+// packets however the work is arranged, and a lone wavefront issues at most
+// one instruction per ~4.6 cycles (VALU) or ~10-12 cycles (LDS) -- measured,
+// tools/valu_probe.hip, tools/lds_probe.hip.  One wavefront doing everything
+// ran at 108 GB/s; modeler + coder at 290 GB/s with the modeler's serial
+// stream (45 VALU + 13 LDS per symbol) as the bottleneck; cutting that stream
+// in two puts three wavefronts on every SIMD for the same LDS.  32 KiB tree +
+// 8 KiB ring = 40 KiB per workgroup -> exactly 4 workgroups = 12 wavefronts/CU.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kPhase = 16;
+constexpr uint32_t kPhase = 8;
 
 struct EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
-    uint32_t ring[2][kPhase][kLanes];          // 8 KiB: cumLo | cumHi << 16
+    uint32_t ring[2][kPhase][2][kLanes];       // 8 KiB: [half][symbol][part][lane], parts add up to cumLo | cumHi << 16
 };
 
-// LDS only: the global loads/stores of either wave stay in flight across the barrier
+// LDS only: the global loads/stores of every wave stay in flight across the barrier
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ void __launch_bounds__(2 * kLanes)
+__device__ __forceinline__ uint2 load8_guarded(const uint8_t *p, size_t avail) {
+    if (avail >= 8) return *reinterpret_cast<const uint2 *>(p);
+    uint32_t w[2] = {0, 0};
+    for (size_t b = 0; b < avail; ++b) w[b >> 2] |= static_cast<uint32_t>(p[b]) << (8u * (b & 3u));
+    return make_uint2(w[0], w[1]);
+}
+
+// One modeler wavefront: `Model` is TopModeler<7> (part 0) or LowModeler<7> (part 1).
+template <typename Model, uint32_t kPart>
+__device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, uint32_t lane, uint32_t len,
+                                            uint32_t len_min, uint32_t n_phases) {
+    uint2 chunk = len ? load8_guarded(in, len) : make_uint2(0, 0);
+    Model model;
+    model.open(lds.tree + 2u * lane_column(lane), chunk.x & 0xFFu);
+    for (uint32_t k = 0; k <= n_phases; ++k) {
+        if (k < n_phases) {
+            const uint32_t base = k * kPhase;
+            const uint2 cur = chunk;
+            if (base + kPhase < len) chunk = load8_guarded(in + base + kPhase, len - (base + kPhase));
+            uint32_t *out = &lds.ring[k & 1u][0][kPart][lane];
+            const uint32_t words[3] = {cur.x, cur.y, chunk.x};
+            if (base + kPhase <= len_min) {
+#pragma unroll
+                for (uint32_t j = 0; j < kPhase; ++j) {
+                    const uint32_t x = (words[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+                    const uint32_t x_next = (words[(j + 1) >> 2] >> (8u * ((j + 1) & 3u))) & 0xFFu;
+                    out[j * 2u * kLanes] = model.step(x, 256u + base + j, x_next);
+                }
+            } else {                       // the phase that holds the file's ragged tail
+#pragma unroll
+                for (uint32_t q = 0; q < 2; ++q) {
+                    uint32_t w = words[q], w_next = words[q + 1];
+#pragma unroll 1
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t i = base + 4u * q + b;
+                        const uint32_t x = w & 0xFFu;
+                        w = (w >> 8) | (w_next << 24);        // next symbol now in the low byte
+                        w_next >>= 8;
+                        if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
+                        out += 2u * kLanes;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(3 * kLanes)
 encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
     __shared__ EncodeLds lds;
 
     const uint32_t lane = threadIdx.x & 63u;
-    // wavefront 0 models, wavefront 1 codes.  The dispatcher was observed
-    // (tools/hwid_probe.hip) to give every SIMD one wavefront 0 and one
-    // wavefront 1 of the four resident workgroups, so each SIMD carries one
-    // modeler and one coder; nothing depends on that placement but speed.
     const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
@@ -102,82 +146,45 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint32_t len_max = wave_max(len);
     const uint32_t len_min = wave_max(~len) ^ 0xFFFFFFFFu;
     const uint32_t n_phases = (len_max + kPhase - 1) / kPhase;
+    const uint8_t *in = src + (live ? start : 0);
 
     if (role == 0) {
-        // ------------------------------ modeler ------------------------------
-        const uint8_t *in = src + (live ? start : 0);
-        uint4 chunk = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
-        ModelerLane<7> model;
-        model.open(lds.tree + 2u * lane_column(lane), chunk.x & 0xFFu);
-        for (uint32_t k = 0; k <= n_phases; ++k) {
-            if (k < n_phases) {
-                const uint32_t base = k * kPhase;
-                const uint4 cur = chunk;
-                if (base + kPhase < len) chunk = load16_guarded(in + base + kPhase, len - (base + kPhase));
-                uint32_t *out = &lds.ring[k & 1u][0][lane];
-                const uint32_t words[5] = {cur.x, cur.y, cur.z, cur.w, chunk.x};
-                if (base + kPhase <= len_min) {
-#pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) {
-                        const uint32_t x = (words[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-                        const uint32_t x_next = (words[(j + 1) >> 2] >> (8u * ((j + 1) & 3u))) & 0xFFu;
-                        out[j * kLanes] = model.step(x, 256u + base + j, x_next);
-                    }
-                } else {                       // the phase that holds the file's ragged tail
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) {
-                        uint32_t w = words[q], w_next = words[q + 1];
-#pragma unroll 1
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            const uint32_t i = base + 4u * q + b;
-                            const uint32_t x = w & 0xFFu;
-                            w = (w >> 8) | (w_next << 24);        // next symbol now in the low byte
-                            w_next >>= 8;
-                            if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
-                            out += kLanes;
-                        }
-                    }
-                }
-            }
-            lds_barrier();
-        }
+        run_modeler<TopModeler<7>, 0>(lds, in, lane, len, len_min, n_phases);
+    } else if (role == 1) {
+        run_modeler<LowModeler<7>, 1>(lds, in, lane, len, len_min, n_phases);
     } else {
         // ------------------------------- coder -------------------------------
         // slot address = (wave-uniform base of this block's first slot) + lane * 8704
         uint8_t *block_slots = dst + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);
         CoderLane coder;
         coder.open(block_slots, lane * kSlot);
-        constexpr uint32_t kGroup = 8;                       // reciprocals are fetched one group ahead
-        Recip rc_next[kGroup];
+        Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
 #pragma unroll
-        for (uint32_t j = 0; j < kGroup; ++j) rc_next[j] = g_recip.r[j];
+        for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[j];
         for (uint32_t k = 0; k <= n_phases; ++k) {
             if (k >= 1) {
                 const uint32_t base = (k - 1u) * kPhase;
-                const uint32_t *in = &lds.ring[(k - 1u) & 1u][0][lane];
+                const uint32_t *in_ring = &lds.ring[(k - 1u) & 1u][0][0][lane];
                 if (base + kPhase <= len_min) {
                     uint32_t cums[kPhase];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in[j * kLanes];
+                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in_ring[j * 2u * kLanes] + in_ring[j * 2u * kLanes + kLanes];
+                    Recip rc[kPhase];
 #pragma unroll
-                    for (uint32_t g = 0; g < kPhase / kGroup; ++g) {
-                        Recip rc[kGroup];
+                    for (uint32_t j = 0; j < kPhase; ++j) rc[j] = rc_next[j];
+                    uint32_t ahead = base + kPhase;                      // wave-uniform
+                    ahead = ahead > kPacket - kPhase ? kPacket - kPhase : ahead;
 #pragma unroll
-                        for (uint32_t j = 0; j < kGroup; ++j) rc[j] = rc_next[j];
-                        uint32_t ahead = base + (g + 1u) * kGroup;           // wave-uniform
-                        ahead = ahead > kPacket - kGroup ? kPacket - kGroup : ahead;
+                    for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[ahead + j];
 #pragma unroll
-                        for (uint32_t j = 0; j < kGroup; ++j) rc_next[j] = g_recip.r[ahead + j];
-#pragma unroll
-                        for (uint32_t j = 0; j < kGroup; ++j) coder.step(cums[g * kGroup + j], rc[j]);
-                    }
+                    for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
                 } else {
 #pragma unroll 1
                     for (uint32_t j = 0; j < kPhase; ++j) {
                         const uint32_t i = base + j;
                         if (i >= len_max) break;
                         const Recip r = g_recip.r[i];
-                        if (i < len) coder.step(in[j * kLanes], r);
+                        if (i < len) coder.step(in_ring[j * 2u * kLanes] + in_ring[j * 2u * kLanes + kLanes], r);
                     }
                 }
             }
@@ -464,7 +471,7 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
-    gpuar::encode_kernel<<<blocks, 2 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+    gpuar::encode_kernel<<<blocks, 3 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
     return check_launch();
 }

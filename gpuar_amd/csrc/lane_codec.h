@@ -460,6 +460,73 @@ struct ModelerLane {
     }
 };
 
+// The modeler split in two, for the three-wavefront encoder: one lane program
+// owns depths [kFirst, kFirst + kDepths) of the tree (its rows of the shared LDS
+// table are disjoint from the other's), optionally the register-resident
+// depths 0 and 1 (kHead) and the x == 255 term (kTail).  Each returns its part
+// of cumLo | cumHi << 16; the parts add up to ModelerLane::step()'s value
+// (both halves stay below 2^16, so the packed add cannot carry across).
+template <uint32_t kRowShift, int kFirst, int kDepths, bool kHead, bool kTail>
+struct PartialModeler {
+    InorderModel<kRowShift> tree;
+    uint32_t root, half0, half1;            // kHead only: depths 0 and 1
+    uint32_t left[kDepths];                 // this part's nodes of the NEXT symbol to account
+    uint16_t *where[kDepths];
+
+    GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
+        tree.col = col;
+        // initial counts, own rows only (the other part initialises its own)
+#pragma unroll 1
+        for (uint32_t row = 0; row < 255u; ++row) {
+            const uint32_t trailing_ones = 31u - GPUAR_CLZ32((row ^ (row + 1u)));
+            const int depth = 7 - static_cast<int>(trailing_ones);
+            if (depth >= kFirst && depth < kFirst + kDepths)
+                *reinterpret_cast<uint16_t *>(col + (row << kRowShift)) = static_cast<uint16_t>(1u << trailing_ones);
+        }
+        root = 128u;
+        half0 = half1 = 64u;
+        const uint32_t xs = first_symbol << kRowShift;
+#pragma unroll
+        for (int k = 0; k < kDepths; ++k) {
+            where[k] = tree.node(xs, kFirst + k);
+            left[k] = *where[k];
+        }
+    }
+
+    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
+        const uint32_t xn = x_next << kRowShift;
+        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
+        uint32_t acc = 0;
+        if (kTail) acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);  // x == 255: cumHi is the whole total
+        if (kHead) {
+            const uint32_t pick0 = (z >> 7) & 0x10001u;
+            acc += GPUAR_MUL24(root, pick0);
+            root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
+            const bool upper_half = x >= 128u;
+            const uint32_t pick1 = (z >> 6) & 0x10001u;
+            acc += GPUAR_MUL24(upper_half ? half1 : half0, pick1);
+            const uint32_t quarter = x >> 6;
+            half0 += quarter == 0u ? 1u : 0u;
+            half1 += quarter == 2u ? 1u : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kDepths; ++k) {
+            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
+            const uint32_t l = left[k];
+            acc += GPUAR_MUL24(l, pick);
+            *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
+            where[k] = tree.node(xn, kFirst + k);
+            left[k] = *where[k];
+        }
+        return acc;
+    }
+};
+
+template <uint32_t kRowShift>
+using TopModeler = PartialModeler<kRowShift, 2, 3, true, false>;    // depths 0..4
+template <uint32_t kRowShift>
+using LowModeler = PartialModeler<kRowShift, 5, 3, false, true>;    // depths 5..7 and the x == 255 term
+
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
 // State: lo and nh = 0xFFFF - hi packed as lo | nh << 16, so that both bounds
 // renormalise with the same left shift (zeros enter lo, ones enter hi).
@@ -749,14 +816,14 @@ struct SubtreeModel {
         owed.b = 2u;
         owed.c = 1u;
         owed.off_b = 2u;
-        owed.off_c = 6u;
+        owed.off_c = 8u;
 #pragma unroll 1
         for (uint32_t r = 0; r < kRecords; ++r) {
             const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
             const uint32_t ab = top | ((top >> 1) << 16);          // a, b0
-            const uint32_t bc = (top >> 1) | ((top >> 2) << 16);   // b1, c0
-            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // c1, c2 ; c3, pad
-            store128(col + (r << kRecShift), ab, bc, cc, cc);
+            const uint32_t xb = (top >> 1) << 16;                  // -, b1
+            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // c0, c1 ; c2, c3
+            store128(col + (r << kRecShift), ab, xb, cc, cc);
         }
     }
 
@@ -764,37 +831,38 @@ struct SubtreeModel {
     // = count of symbols left of the current node's range, `upper` = count of
     // symbols left of its right end; the target is compared against below +
     // left-count directly.  Every decision is kept as "went LEFT" because that
-    // is what the node update adds; `nsym` collects the complemented symbol bits.
-    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nsym) {
+    // is what the node update adds.  Record layout (chosen so that the two
+    // candidates of a decision sit in the same half of two dwords and one
+    // select picks both grandchildren at once):
+    //     w0 = a | b0 << 16     w1 = - | b1 << 16     w2 = c0 | c1 << 16     w3 = c2 | c3 << 16
+    // Returns the three decisions as complemented symbol bits (0..7, first = MSB).
+    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nbits) {
         const uint32_t *w = q.w;
-        const uint32_t a = w[0] & 0xFFFFu, b0 = w[0] >> 16, b1 = w[1] & 0xFFFFu, c0 = w[1] >> 16;
-        const uint32_t c1 = w[2] & 0xFFFFu, c2 = w[2] >> 16, c3 = w[3] & 0xFFFFu;
+        const uint32_t a = w[0] & 0xFFFFu;
         const uint32_t sa = below + a;
         const bool la = target < sa;
         below = la ? below : sa;
         upper = la ? sa : upper;
-        const uint32_t b = la ? b0 : b1;
-        const uint32_t cl = la ? c0 : c2, ch = la ? c1 : c3;
+        const uint32_t b = (la ? w[0] : w[1]) >> 16;
+        const uint32_t cc = la ? w[2] : w[3];                 // both grandchildren under the chosen child
         const uint32_t sb = below + b;
         const bool lb = target < sb;
         below = lb ? below : sb;
         upper = lb ? sb : upper;
-        const uint32_t c = lb ? cl : ch;
+        const uint32_t c = lb ? (cc & 0xFFFFu) : (cc >> 16);
         const uint32_t sc = below + c;
         const bool lc = target < sc;
         below = lc ? below : sc;
         upper = lc ? sc : upper;
-        nsym = nsym + nsym + (la ? 1u : 0u);
-        nsym = nsym + nsym + (lb ? 1u : 0u);
-        nsym = nsym + nsym + (lc ? 1u : 0u);
-        // fields: a = 0, b0 = 1, b1 = 2, c0..c3 = 3..6 (2 bytes each)
         Path p;
         p.rec = rec;
         p.a = a + (la ? 1u : 0u);
         p.b = b + (lb ? 1u : 0u);
         p.c = c + (lc ? 1u : 0u);
-        p.off_b = la ? 2u : 4u;
-        p.off_c = (la ? 6u : 10u) + (lb ? 0u : 2u);
+        p.off_b = la ? 2u : 6u;
+        p.off_c = (la ? 8u : 12u) + (lb ? 0u : 2u);
+        // (off_c - 8) / 2 = 2 * !la + !lb : the first two symbol bits, already in place
+        nbits = ((p.off_c - 8u) ^ 6u) | (lc ? 1u : 0u);       // complemented bits la lb lc
         return p;
     }
     GPUAR_LANE void write_back(const Path &p) {
@@ -820,23 +888,25 @@ struct SubtreeModel {
         const bool l1 = target < s1;
         below = l1 ? below : s1;
         upper = l1 ? s1 : upper;
-        uint32_t nsym = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented bits, MSB first
-        uint8_t *rec_mid = col + ((nsym ^ 3u) << kRecShift);
+        const uint32_t n2 = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);  // complemented top two bits
+        uint8_t *rec_mid = col + ((n2 ^ 3u) << kRecShift);
         Quad q_mid = load128(rec_mid);                        // ds_read_b128 #1 ...
         GPUAR_PIN_LOAD(q_mid);
         write_back(owed);                                     // ... with the previous symbol's write-back behind it
         root += l0 ? 1u : 0u;                                 // register nodes: also in the shadow of read #1
         half0 += (l0 && l1) ? 1u : 0u;
         half1 += (!l0 && l1) ? 1u : 0u;
-        const Path p_mid = decide3(rec_mid, q_mid, target, below, upper, nsym);
-        uint8_t *rec_low = col + ((4u + (nsym ^ 31u)) << kRecShift);
+        uint32_t n_mid, n_low;
+        const Path p_mid = decide3(rec_mid, q_mid, target, below, upper, n_mid);
+        const uint32_t n5 = (n2 << 3) | n_mid;                // complemented top five bits
+        uint8_t *rec_low = col + ((4u + (n5 ^ 31u)) << kRecShift);
         Quad q_low = load128(rec_low);                        // ds_read_b128 #2 ...
         GPUAR_PIN_LOAD(q_low);
         write_back(p_mid);                                    // ... with the first write-back behind it
-        owed = decide3(rec_low, q_low, target, below, upper, nsym);
+        owed = decide3(rec_low, q_low, target, below, upper, n_low);
         cum_lo = below;
         cum_hi = upper;
-        return nsym ^ 255u;
+        return ((n5 << 3) | n_low) ^ 255u;
     }
 
     // issue the write-back still owed (call once after the last symbol; harmless if repeated)

@@ -60,6 +60,33 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     return any_overflow;
 }
 
+// The three-wavefront split (TopModeler + LowModeler + CoderLane).
+int emu_encode_slots_split3(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+{
+    int any_overflow = 0;
+    const size_t np = (n_bytes + kPacket - 1) / kPacket;
+    std::vector<uint16_t> tree(256);
+    for (size_t p = 0; p < np; ++p) {
+        const size_t off = p * kPacket;
+        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
+        TopModeler<1> top;
+        LowModeler<1> low;
+        top.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
+        low.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
+        CoderLane coder;
+        coder.open(slots, static_cast<uint32_t>(p * kSlot));
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t next = i + 1 < len ? in[off + i + 1] : 0u;
+            const uint32_t cums = top.step(in[off + i], 256u + i, next) + low.step(in[off + i], 256u + i, next);
+            coder.step(cums, kRecip.r[i]);
+        }
+        bool ov;
+        coder.finish(len, ov);
+        any_overflow |= ov ? 1 : 0;
+    }
+    return any_overflow;
+}
+
 // pkt_offsets: np+1 byte offsets into `stream`; out: np * 8192 bytes.
 // Returns the number of packets flagged bad.
 int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)

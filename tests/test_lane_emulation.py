@@ -35,6 +35,8 @@ def emu():
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_encode_slots_split.restype = C.c_int
     lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_split3.restype = C.c_int
+    lib.emu_encode_slots_split3.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_decode_stream2.restype = C.c_int
@@ -48,7 +50,7 @@ def emu_encode(lib, data: np.ndarray, split=False):
     npk = (data.size + 8191) // 8192
     slots = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
     src = np.ascontiguousarray(data)
-    fn = lib.emu_encode_slots_split if split else lib.emu_encode_slots
+    fn = {False: lib.emu_encode_slots, True: lib.emu_encode_slots_split, 3: lib.emu_encode_slots_split3}[split]
     ov = fn(src.ctypes.data_as(u8p), src.size, slots.ctypes.data_as(u8p))
     return slots, npk, ov
 
@@ -80,11 +82,13 @@ def test_reciprocal_table_is_exact(emu):
 def test_split_encoder_matches_reference_fixture(emu, port_oracle, c):
     """InorderModel + CoderLane: what the modeler / coder wavefronts of the encode kernel run."""
     data = case_input(c)
-    slots, npk, ov = emu_encode(emu, data, split=True)
-    assert ov == 0
-    stream, _ = slots_to_stream(slots, npk)
-    assert stream.size == c["stream_len"]
-    assert np.array_equal(stream, port_oracle.encode_stream(data))
+    want = port_oracle.encode_stream(data)
+    for split in (True, 3):       # two-part (modeler + coder) and three-part (top + low modeler + coder) forms
+        slots, npk, ov = emu_encode(emu, data, split=split)
+        assert ov == 0
+        stream, _ = slots_to_stream(slots, npk)
+        assert stream.size == c["stream_len"]
+        assert np.array_equal(stream, want)
 
 
 @pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
@@ -117,8 +121,9 @@ def test_lane_codec_random_packets(emu, port_oracle):
         slots, npk, ov = emu_encode(emu, data)
         stream, offs = slots_to_stream(slots, npk)
         assert ov == 0 and np.array_equal(stream, port_oracle.encode_stream(data)), trial
-        slots2, _, ov2 = emu_encode(emu, data, split=True)
-        assert ov2 == 0 and np.array_equal(slots2, slots), trial
+        for split in (True, 3):
+            slots2, _, ov2 = emu_encode(emu, data, split=split)
+            assert ov2 == 0 and np.array_equal(slots2, slots), (trial, split)
         out, bad = emu_decode(emu, stream, offs, npk)
         assert bad == 0 and np.array_equal(out[:n], data), trial
         out2, bad2 = emu_decode(emu, stream, offs, npk, form=2)

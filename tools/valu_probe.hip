@@ -10,17 +10,33 @@ template <int KIND>
 __global__ void __launch_bounds__(64) probe(uint32_t *out, int iters, int dyn_unused) {
     extern __shared__ uint8_t pad[];
     uint32_t a = threadIdx.x, b = blockIdx.x + 1, c = 7, d = 9;
+    unsigned long long w = threadIdx.x;
     for (int i = 0; i < iters; ++i) {
-        if (KIND == 0) asm volatile(REP64("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));          // 128 adds, 2 chains
-        if (KIND == 1) asm volatile(REP64("v_add_u32 %0, %0, %2\n v_add_u32 %0, %0, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));          // 128 adds, 1 chain
-        if (KIND == 2) asm volatile(REP64("v_and_or_b32 %0, %0, %2, %3\n v_lshrrev_b32 %1, 1, %1\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-        if (KIND == 3) asm volatile(REP64("v_mul_u32_u24 %0, %0, %2\n v_mad_u32_u24 %1, %1, %2, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-        if (KIND == 4) asm volatile(REP64("v_mul_hi_u32 %0, %0, %2\n v_add_u32 %1, %1, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-        if (KIND == 5) asm volatile(REP64("v_cmp_lt_u32 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "vcc");
-        if (KIND == 6) asm volatile(REP64("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-        if (KIND == 7) asm volatile(REP64("s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, %3\n") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "s20", "scc");
+        if (KIND == 0) asm volatile(REP64("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 1) asm volatile(REP64("v_lshrrev_b32 %0, 1, %0\n v_lshrrev_b32 %1, 1, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 2) asm volatile(REP64("v_and_b32 %0, %0, %2\n v_and_b32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 3) asm volatile(REP64("v_and_or_b32 %0, %0, %2, %3\n v_and_or_b32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 4) asm volatile(REP64("v_lshl_or_b32 %0, %0, 1, %3\n v_lshl_or_b32 %1, %1, 1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 5) asm volatile(REP64("v_xad_u32 %0, %0, 1, %3\n v_xad_u32 %1, %1, 1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 6) asm volatile(REP64("v_add3_u32 %0, %0, %2, %3\n v_add3_u32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 7) asm volatile(REP64("v_bfe_u32 %0, %0, 1, 20\n v_bfe_u32 %1, %1, 1, 20\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 8) asm volatile(REP64("v_mul_u32_u24 %0, %0, %2\n v_mul_u32_u24 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 9) asm volatile(REP64("v_mad_u32_u24 %0, %0, %2, %3\n v_mad_u32_u24 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 10) asm volatile(REP64("v_mul_hi_u32 %0, %0, %2\n v_mul_hi_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 11) asm volatile(REP64("v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 12) asm volatile(REP64("v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 13) asm volatile(REP64("v_cmp_lt_u32 vcc, %0, %2\n v_cmp_lt_u32 vcc, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 14) asm volatile(REP64("v_cmp_lt_u32_e64 s[22:23], %0, %2\n v_cmp_lt_u32_e64 s[22:23], %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 15) asm volatile(REP64("v_ffbh_u32 %0, %0\n v_ffbh_u32 %1, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 16) asm volatile(REP64("v_not_b32 %0, %0\n v_not_b32 %1, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 17) asm volatile(REP64("v_perm_b32 %0, %0, %2, %3\n v_perm_b32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 18) asm volatile(REP64("v_alignbit_b32 %0, %0, %2, %3\n v_alignbit_b32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 19) asm volatile(REP64("v_lshrrev_b64 %4, 3, %4\n v_lshrrev_b64 %4, 3, %4\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 20) asm volatile(REP64("v_sub_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n v_sub_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 21) asm volatile(REP64("v_bfm_b32 %0, %0, %2\n v_bfm_b32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 22) asm volatile(REP64("v_subb_co_u32 %0, vcc, %0, %2, vcc\n v_subb_co_u32 %1, vcc, %1, %2, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
     }
-    if (a + b == 0x12345) out[blockIdx.x] = a + pad[0];
+    if (a + b + (uint32_t)w == 0x12345) out[blockIdx.x] = a + pad[0];
 }
 template <int KIND>
 void run(const char *name) {
@@ -47,13 +63,28 @@ void run(const char *name) {
     hipFree(d);
 }
 int main() {
-    run<0>("v_add_u32 x2 independent chains");
-    run<1>("v_add_u32 single dependent chain");
-    run<2>("v_and_or_b32 + v_lshrrev_b32");
-    run<3>("v_mul_u32_u24 + v_mad_u32_u24");
-    run<4>("v_mul_hi_u32 + v_add_u32");
-    run<5>("v_cmp_lt_u32 + v_cndmask_b32");
-    run<6>("v_fma_f32 x2 (reference point)");
-    run<7>("s_add_u32 + v_add_u32");
+    run<0>("v_add_u32 (VOP2)");
+    run<1>("v_lshrrev_b32 (VOP2)");
+    run<2>("v_and_b32 (VOP2)");
+    run<3>("v_and_or_b32 (VOP3)");
+    run<4>("v_lshl_or_b32 (VOP3)");
+    run<5>("v_xad_u32 (VOP3)");
+    run<6>("v_add3_u32 (VOP3)");
+    run<7>("v_bfe_u32 (VOP3)");
+    run<8>("v_mul_u32_u24 (VOP2)");
+    run<9>("v_mad_u32_u24 (VOP3)");
+    run<10>("v_mul_hi_u32 (VOP3)");
+    run<11>("v_cndmask_b32 vcc (VOP2)");
+    run<12>("v_cndmask_b32 sgpr (VOP3)");
+    run<13>("v_cmp_lt_u32 -> vcc (VOPC)");
+    run<14>("v_cmp_lt_u32 -> sgpr (VOP3)");
+    run<15>("v_ffbh_u32 (VOP1)");
+    run<16>("v_not_b32 (VOP1)");
+    run<17>("v_perm_b32 (VOP3)");
+    run<18>("v_alignbit_b32 (VOP3)");
+    run<19>("v_lshrrev_b64 (VOP3)");
+    run<20>("v_sub_u32_sdwa");
+    run<21>("v_bfm_b32 (VOP3)");
+    run<22>("v_subb_co_u32 (VOP2)");
     return 0;
 }
