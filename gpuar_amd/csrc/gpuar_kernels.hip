@@ -85,27 +85,33 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ uint2 load8_guarded(const uint8_t *p, size_t avail) {
-    if (avail >= 8) return *reinterpret_cast<const uint2 *>(p);
-    uint32_t w[2] = {0, 0};
+__device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) {
+    if (avail >= 16) return *reinterpret_cast<const uint4 *>(p);
+    uint32_t w[4] = {0, 0, 0, 0};
     for (size_t b = 0; b < avail; ++b) w[b >> 2] |= static_cast<uint32_t>(p[b]) << (8u * (b & 3u));
-    return make_uint2(w[0], w[1]);
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // One modeler wavefront: `Model` is TopModeler<7> (part 0) or LowModeler<7> (part 1).
 template <typename Model, uint32_t kPart>
 __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, uint32_t lane, uint32_t len,
                                             uint32_t len_min, uint32_t n_phases) {
-    uint2 chunk = len ? load8_guarded(in, len) : make_uint2(0, 0);
+    // 16 input bytes per lane every other phase (one 128-byte line is touched 8 times, not 16)
+    uint4 cur = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
+    uint4 nxt = len > 16u ? load16_guarded(in + 16, len - 16u) : make_uint4(0, 0, 0, 0);
     Model model;
-    model.open(lds.tree + 2u * lane_column(lane), chunk.x & 0xFFu);
+    model.open(lds.tree + 2u * lane_column(lane), cur.x & 0xFFu);
     for (uint32_t k = 0; k <= n_phases; ++k) {
         if (k < n_phases) {
             const uint32_t base = k * kPhase;
-            const uint2 cur = chunk;
-            if (base + kPhase < len) chunk = load8_guarded(in + base + kPhase, len - (base + kPhase));
+            const bool odd = (k & 1u) != 0u;                   // wave-uniform: second half of `cur`
+            const uint32_t words[3] = {odd ? cur.z : cur.x, odd ? cur.w : cur.y, odd ? nxt.x : cur.z};
+            if (odd) {                                         // `cur` is used up after this phase
+                cur = nxt;
+                const uint32_t ahead = base + kPhase + 16u;
+                if (ahead < len) nxt = load16_guarded(in + ahead, len - ahead);
+            }
             uint32_t *out = &lds.ring[k & 1u][0][kPart][lane];
-            const uint32_t words[3] = {cur.x, cur.y, chunk.x};
             if (base + kPhase <= len_min) {
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {
