@@ -190,3 +190,24 @@ def test_round_trip_properties_at_scale(H):
     want = O.best().encode_stream(host)
     got = d_stream[int(d_off[p0].item()):int(d_off[p0 + 32].item())].cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_compaction_offsets_beyond_4gib(H):
+    """Maximum sizes: 5 GiB of uniform data compacts to > 4 GiB, so packet offsets must be 64-bit
+    all the way (the reference's container cannot represent this; SURVEY.md section 7 risk 4)."""
+    n = 5 << 30
+    d_in = H.generate("uniform", 7, n)
+    npk = H.packet_count(n)
+    d_slots = H.encode(d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    total = int(d_off[-1].item())
+    assert total > (1 << 32)
+    clen = d_slots.view(npk, 8704)[:, 0].to(torch.int64) | (d_slots.view(npk, 8704)[:, 1].to(torch.int64) << 8)
+    assert int(clen.sum().item()) == total
+    assert bool((d_off[1:] - d_off[:-1] == clen).all())
+    # the last packets decode from the compacted stream (offsets above 4 GiB in use)
+    del d_slots
+    d_back = H.decode_stream(d_stream, d_off, npk)
+    assert torch.equal(d_back[n - (1 << 20):n], d_in[n - (1 << 20):])
+    assert torch.equal(d_back[:1 << 20], d_in[:1 << 20])
+    assert H.status() == 0
