@@ -831,27 +831,31 @@ struct SubtreeModel {
     // = count of symbols left of the current node's range, `upper` = count of
     // symbols left of its right end; the target is compared against below +
     // left-count directly.  Every decision is kept as "went LEFT" because that
-    // is what the node update adds.  Record layout (chosen so that the two
+    // is what the node update adds.  The decoder never forms the quotient
+    // unscaled = floor(num / range) of getUnscaledCode (:703-716): for an integer
+    // s, unscaled < s  <=>  num < s * range, so each decision is one 24-bit
+    // multiply and a compare -- exact, and no division by the lane-varying
+    // range.  Record layout (chosen so that the two
     // candidates of a decision sit in the same half of two dwords and one
     // select picks both grandchildren at once):
     //     w0 = a | b0 << 16     w1 = - | b1 << 16     w2 = c0 | c1 << 16     w3 = c2 | c3 << 16
     // Returns the three decisions as complemented symbol bits (0..7, first = MSB).
-    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t target, uint32_t &below, uint32_t &upper, uint32_t &nbits) {
+    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t num, uint32_t range, uint32_t &below, uint32_t &upper, uint32_t &nbits) {
         const uint32_t *w = q.w;
         const uint32_t a = w[0] & 0xFFFFu;
         const uint32_t sa = below + a;
-        const bool la = target < sa;
+        const bool la = num < GPUAR_MUL24_VV(sa, range);
         below = la ? below : sa;
         upper = la ? sa : upper;
         const uint32_t b = (la ? w[0] : w[1]) >> 16;
         const uint32_t cc = la ? w[2] : w[3];                 // both grandchildren under the chosen child
         const uint32_t sb = below + b;
-        const bool lb = target < sb;
+        const bool lb = num < GPUAR_MUL24_VV(sb, range);
         below = lb ? below : sb;
         upper = lb ? sb : upper;
         const uint32_t c = lb ? (cc & 0xFFFFu) : (cc >> 16);
         const uint32_t sc = below + c;
-        const bool lc = target < sc;
+        const bool lc = num < GPUAR_MUL24_VV(sc, range);
         below = lc ? below : sc;
         upper = lc ? sc : upper;
         Path p;
@@ -871,21 +875,22 @@ struct SubtreeModel {
         store16(p.rec + p.off_c, p.c);
     }
 
-    // the symbol s with cum(s) <= target < cum(s+1); cum_lo = cum(s), cum_hi = cum(s+1).
-    // Memory-safe for any target (a target >= total simply walks right).
+    // The symbol s with cum(s) <= floor(num / range) < cum(s+1); cum_lo = cum(s),
+    // cum_hi = cum(s+1).  Memory-safe for any num (a value beyond the model's
+    // total simply walks right).
     // Order of LDS traffic (LDS operations of a wavefront complete in order):
     //   read mid record -> write back the PREVIOUS symbol's low record (mid and
     //   low records are disjoint; a later read of the same low record comes
     //   after this write) -> read low record -> write back the mid record ->
     //   (low record's write-back is owed to the next call / flush()).
     // Each write-back thus sits in the shadow of a read instead of in front of it.
-    GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
-        const bool l0 = target < root;
+    GPUAR_LANE uint32_t decode_step(uint32_t num, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
+        const bool l0 = num < GPUAR_MUL24_VV(root, range);
         uint32_t below = l0 ? 0u : root;
         uint32_t upper = l0 ? root : total;
         const uint32_t h = l0 ? half0 : half1;
         const uint32_t s1 = below + h;
-        const bool l1 = target < s1;
+        const bool l1 = num < GPUAR_MUL24_VV(s1, range);
         below = l1 ? below : s1;
         upper = l1 ? s1 : upper;
         const uint32_t n2 = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);  // complemented top two bits
@@ -897,13 +902,13 @@ struct SubtreeModel {
         half0 += (l0 && l1) ? 1u : 0u;
         half1 += (!l0 && l1) ? 1u : 0u;
         uint32_t n_mid, n_low;
-        const Path p_mid = decide3(rec_mid, q_mid, target, below, upper, n_mid);
+        const Path p_mid = decide3(rec_mid, q_mid, num, range, below, upper, n_mid);
         const uint32_t n5 = (n2 << 3) | n_mid;                // complemented top five bits
         uint8_t *rec_low = col + ((4u + (n5 ^ 31u)) << kRecShift);
         Quad q_low = load128(rec_low);                        // ds_read_b128 #2 ...
         GPUAR_PIN_LOAD(q_low);
         write_back(p_mid);                                    // ... with the first write-back behind it
-        owed = decide3(rec_low, q_low, target, below, upper, n_low);
+        owed = decide3(rec_low, q_low, num, range, below, upper, n_low);
         cum_lo = below;
         cum_hi = upper;
         return ((n5 << 3) | n_low) ^ 255u;
@@ -990,20 +995,13 @@ struct DecoderLane2 {
         const uint32_t total = 256u + i;
         const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
         const uint32_t num = GPUAR_MUL24(((code - lo) & 0xFFFFu) + 1u, total) - 1u;
-        uint32_t q = GPUAR_RCP_QUOT(num, range);
-        int32_t rem = static_cast<int32_t>(num - GPUAR_MUL24_VV(q, range));
-        if (rem < 0) {
-            --q;
-            rem += static_cast<int32_t>(range);
-        }
-        if (rem >= static_cast<int32_t>(range)) ++q;
-        // No symbol owns a code value >= total (:873-877, where the reference
-        // stops decoding the packet).  Such a packet is malformed: flag it and
-        // keep going on a clamped target -- the walk stays inside the tree and
+        // No symbol owns a code value with floor(num / range) >= total (:873-877,
+        // where the reference stops decoding the packet).  Such a packet is
+        // malformed: flag it and keep going -- the walk stays inside the tree and
         // the output inside its 8192 bytes whatever the bits are.
-        bad = bad || q >= total;
+        bad = bad || num >= GPUAR_MUL24(range, total);
         uint32_t cum_lo, cum_hi;
-        const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
+        const uint32_t sym = model.decode_step(num, range, total, cum_lo, cum_hi);
         narrow(lo, hi, cum_lo, cum_hi, rc);
         const Renorm r = renorm_split(lo, hi);
         // e agree-shifts and u underflow-shifts pull e + u (<= 31) fresh bits in
