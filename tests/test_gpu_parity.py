@@ -211,3 +211,43 @@ def test_compaction_offsets_beyond_4gib(H):
     assert torch.equal(d_back[n - (1 << 20):n], d_in[n - (1 << 20):])
     assert torch.equal(d_back[:1 << 20], d_in[:1 << 20])
     assert H.status() == 0
+
+
+def test_many_mixed_packets_against_oracle(H, oracle_port):
+    """2048 packets, every one from a different source model (uniform, k-symbol, geometric, long
+    runs, ramps, near-midpoint pairs, constant): slot-for-slot equality with the oracle, then decode."""
+    rng = np.random.default_rng(20261003)
+    npk = 2048
+    data = np.empty(npk * 8192, dtype=np.uint8)
+    for p in range(npk):
+        view = data[p * 8192:(p + 1) * 8192]
+        mode = p % 8
+        if mode == 0:
+            view[:] = rng.integers(0, 256, 8192, dtype=np.uint8)
+        elif mode == 1:
+            view[:] = rng.integers(0, int(rng.integers(1, 9)), 8192, dtype=np.uint8) * int(rng.integers(1, 32))
+        elif mode == 2:
+            view[:] = (rng.geometric(float(rng.uniform(0.02, 0.5)), 8192) % 256).astype(np.uint8)
+        elif mode == 3:
+            view[:] = np.repeat(rng.integers(0, 256, 8192 // 32, dtype=np.uint8), 32)
+        elif mode == 4:
+            view[:] = (np.arange(8192) * int(rng.integers(1, 255))) % 256
+        elif mode == 5:
+            view[:] = rng.choice(np.array([0x7F, 0x80], dtype=np.uint8), 8192)
+        elif mode == 6:
+            view[:] = int(rng.integers(0, 256))
+        else:
+            view[:] = np.sort(rng.integers(0, 256, 8192, dtype=np.uint8))
+    want, total = oracle_port.encode_slots(data)
+    d_slots = H.encode(torch.from_numpy(data).cuda())
+    got = d_slots.cpu().numpy()
+    want_len = want.reshape(npk, 8704)[:, 0].astype(np.int64) | (want.reshape(npk, 8704)[:, 1].astype(np.int64) << 8)
+    got_len = got.reshape(npk, 8704)[:, 0].astype(np.int64) | (got.reshape(npk, 8704)[:, 1].astype(np.int64) << 8)
+    assert np.array_equal(want_len, got_len)
+    mask = np.arange(8704)[None, :] < want_len[:, None]
+    assert np.array_equal(got.reshape(npk, 8704)[mask], want.reshape(npk, 8704)[mask])
+    d_stream, d_off = H.compact(d_slots, npk)
+    assert int(d_off[-1].item()) == total
+    assert np.array_equal(H.decode(d_slots, npk).cpu().numpy(), data)
+    assert np.array_equal(H.decode_stream(d_stream, d_off, npk).cpu().numpy(), data)
+    assert H.status() == 0
