@@ -207,10 +207,9 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 // Decode: replaces garDecompress + arDecompress (:916-934, 848-892)
 // ---------------------------------------------------------------------------
-constexpr uint32_t kDecodeRecords = 36;
 __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, const uint8_t *limit,
                                             uint8_t *out, bool live) {
-    DecoderLane2<10> dec;
+    DecoderLane<10> dec;
     dec.open(col, pkt, limit, live);
     const uint32_t len_max = wave_max(dec.ulen);
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;

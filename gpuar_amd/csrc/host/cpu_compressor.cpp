@@ -19,21 +19,31 @@ namespace {
 const gpuar::RecipTable kRecip = gpuar::RecipTable();
 constexpr size_t kBatchPackets = 4096;   // 32 MiB of input per batch
 
+// one packet through the same three lane programs the GPU's encoder wavefronts run
 size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
-    uint16_t tree[gpuar::kTreeRows];
-    gpuar::EncoderLane<1> enc;
-    enc.open(tree, slot);
-    for (uint32_t i = 0; i < len; ++i) enc.step(in[i], i, kRecip.r[i]);
+    uint16_t table[gpuar::kTreeRows];
+    uint8_t *col = reinterpret_cast<uint8_t *>(table);
+    gpuar::TopModeler<1> top;
+    gpuar::LowModeler<1> low;
+    top.open(col, in[0]);
+    low.open(col, in[0]);
+    gpuar::CoderLane coder;
+    coder.open(slot, 0);
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t x = in[i], next = i + 1 < len ? in[i + 1] : 0u;
+        coder.step(top.step(x, 256u + i, next) + low.step(x, 256u + i, next), kRecip.r[i]);
+    }
     bool overflowed = false;
-    const uint32_t clen = enc.finish(slot, len, overflowed);
+    const uint32_t clen = coder.finish(len, overflowed);
     if (overflowed) throw std::runtime_error("a packet outgrew its 8704-byte slot");
     return clen;
 }
 
+// ... and the decoder lane program
 size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
-    uint16_t tree[gpuar::kTreeRows];
-    gpuar::DecoderLane<1> dec;
-    dec.open(tree, pkt, limit, true);
+    alignas(16) uint8_t records[gpuar::kDecodeRecords * 16];
+    gpuar::DecoderLane<4> dec;
+    dec.open(records, pkt, limit, true);
     for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], out);
     dec.finish(out);
     if (dec.bad) throw std::runtime_error("Incorrect file format");

@@ -29,14 +29,6 @@
 #define GPUAR_MUL24_VV(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
-// quotient ESTIMATE (v_cvt, v_rcp_f32, v_mul, v_cvt): within 1 of floor(num/den)
-// for num < 2^30, den <= 2^16, quotient < 2^14; the callers correct it exactly
-#define GPUAR_RCP_QUOT(num, den) \
-    static_cast<uint32_t>(static_cast<float>(num) * __builtin_amdgcn_rcpf(static_cast<float>(den)))
-// keep values in registers at this point: stops hipcc from sinking LDS reads
-// into the branches that consume them (which would serialise the round trips)
-#define GPUAR_PIN7(a, b, c, d, e, f, g) \
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g))
 // the load that produces q is issued here, before any later store (no wait is implied)
 #define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
@@ -49,15 +41,6 @@
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
 #define GPUAR_BFM(w, off) (((1u << ((w) & 31u)) - 1u) << ((off) & 31u))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
-#ifdef GPUAR_LANE_TEST_PERTURB
-// test harness only: the estimate is deliberately off by one both ways on a
-// rotating schedule, so the exact correction that follows it is exercised
-#define GPUAR_RCP_QUOT(num, den) \
-    (static_cast<uint32_t>((num) / (den)) + (((num) % 3u) == 0u ? 1u : (((num) % 3u) == 1u && (num) >= (den) ? 0xFFFFFFFFu : 0u)))
-#else
-#define GPUAR_RCP_QUOT(num, den) static_cast<uint32_t>((num) / (den))
-#endif
-#define GPUAR_PIN7(a, b, c, d, e, f, g) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #endif
@@ -68,7 +51,8 @@ constexpr uint32_t kPacket = GPUAR_PACKET_BYTES;   // 8192
 constexpr uint32_t kSlot = GPUAR_SLOT_BYTES;       // 8704
 constexpr uint32_t kHdr = GPUAR_PACKET_HEADER_BYTES;
 constexpr uint32_t kLanes = 64;
-constexpr uint32_t kTreeRows = 256;                // row 0 unused, rows 1..255 = heap nodes
+constexpr uint32_t kTreeRows = 256;                // rows of the encoder's node table (255 used)
+constexpr uint32_t kDecodeRecords = 36;            // 16-byte subtree records of the decoder's model
 
 // ---------------------------------------------------------------------------
 // Exact division by the wave-uniform model total d = 256 + i, i in [0, 8192).
@@ -97,66 +81,6 @@ struct RecipTable {
 };
 
 GPUAR_LANE uint32_t div_total(uint32_t n, Recip rc) { return GPUAR_MULHI(n, rc.mul) >> rc.shift; }
-
-// ---------------------------------------------------------------------------
-// Adaptive order-0 model: complete binary tree of "count of symbols in my left
-// subtree", heap order, one u16 per node.  `col` points at this lane's column;
-// consecutive nodes are `stride` u16 apart (64 on the GPU: node-major,
-// lane-minor, so every lane keeps to its own LDS bank).
-// Equivalent to the reference's Fenwick tree (getRange/update :215-238):
-// both give exact prefix sums of the same counts.
-// ---------------------------------------------------------------------------
-template <uint32_t kStride>
-struct ModelTree {
-    uint16_t *col;
-
-    // every symbol starts with count 1 (:403-419)
-    GPUAR_LANE void reset() {
-#pragma unroll 1
-        for (uint32_t node = 1; node < kTreeRows; ++node) {
-            const uint32_t depth = 31u - GPUAR_CLZ32(node);
-            col[node * kStride] = static_cast<uint16_t>(128u >> depth);
-        }
-    }
-
-    // Known symbol x: returns cumLo | cumHi << 16 (counts of symbols < x and
-    // <= x, before the update) and adds 1 to x's count.  cumHi = cumLo(x+1):
-    // the path of x+1 leaves the path of x at x's lowest zero bit and has only
-    // zero bits below it, so both sums run over x's own eight nodes.
-    GPUAR_LANE uint32_t encode_step(uint32_t x, uint32_t total) {
-        const uint32_t y = x + 1;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t node = (1u << k) | (x >> (8 - k));
-            const uint32_t left = col[node * kStride];
-            const uint32_t bx = (x >> (7 - k)) & 1u;
-            const uint32_t by = (y >> (7 - k)) & 1u;
-            acc += left * (bx | (by << 16));
-            col[node * kStride] = static_cast<uint16_t>(left + (bx ^ 1u));
-        }
-        return (x == 255u) ? ((acc & 0xFFFFu) | (total << 16)) : acc;
-    }
-
-    // Decoder: the symbol s with cum(s) <= target < cum(s+1)
-    // (getSymbolFromProbability :727-763), found and updated in one walk.
-    GPUAR_LANE uint32_t decode_step(uint32_t target, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
-        uint32_t node = 1, t = target, below = 0, span = total;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t left = col[node * kStride];
-            const bool right = t >= left;
-            col[node * kStride] = static_cast<uint16_t>(left + (right ? 0u : 1u));
-            t -= right ? left : 0u;
-            below += right ? left : 0u;
-            span = right ? span - left : left;
-            node = 2u * node + (right ? 1u : 0u);
-        }
-        cum_lo = below;
-        cum_hi = below + span;
-        return node - 256u;
-    }
-};
 
 // Interval narrowing (applySymbolRange :256-299); 16-bit state in 32-bit registers.
 GPUAR_LANE void narrow(uint32_t &lo, uint32_t &hi, uint32_t cum_lo, uint32_t cum_hi, Recip rc) {
@@ -230,139 +154,28 @@ GPUAR_LANE void store32(uint8_t *at, uint32_t v) {
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// Bit sink: MSB-first bits -> big-endian dwords in the packet slot
-// (writeBit/putChar :76-84,128-151).  `body` is slot + 4, 4-byte aligned.
-// ---------------------------------------------------------------------------
-struct BitSink {
-    uint64_t acc;     // low `n` bits are pending output, oldest bit highest
-    uint32_t n;       // < 32 between calls
-    uint32_t pos;     // bytes already stored after the 4-byte packet header
-    uint8_t *body;
-    bool overflow;
-
-    GPUAR_LANE void open(uint8_t *b) {
-        acc = 0;
-        n = 0;
-        pos = 0;
-        body = b;
-        overflow = false;
-    }
-
-    GPUAR_LANE void put(uint32_t bits, uint32_t count) {  // count <= 32
-        acc = (acc << count) | bits;
-        n += count;
-        if (n >= 32u) {
-            n -= 32u;
-            const uint32_t word = static_cast<uint32_t>(acc >> n);
-            if (pos + 4u <= kSlot - kHdr) {
-                const uint32_t be = bswap32(word);
-                memcpy(body + pos, &be, 4);
-            } else {
-                overflow = true;
-            }
-            pos += 4u;
-        }
-    }
-
-    // `count` copies of `bit`; count is unbounded in principle
-    GPUAR_LANE void put_run(uint32_t bit, uint32_t count) {
-        const uint32_t ones = 0u - bit;
-        while (count >= 32u) {
-            put(ones, 32u);
-            count -= 32u;
-        }
-        if (count) put(ones & ((1u << count) - 1u), count);
-    }
-
-    // zero-pad to a byte boundary and store the tail (writeClose :430-439);
-    // returns the body length in bytes
-    GPUAR_LANE uint32_t close() {
-        const uint32_t tail_bytes = (n + 7u) >> 3;
-        const uint32_t word = n ? static_cast<uint32_t>(acc << (32u - n)) : 0u;
-        for (uint32_t b = 0; b < tail_bytes; ++b) {
-            if (pos + b < kSlot - kHdr) {
-                body[pos + b] = static_cast<uint8_t>(word >> (24u - 8u * b));
-            } else {
-                overflow = true;
-            }
-        }
-        return pos + tail_bytes;
-    }
-};
-
-// ---------------------------------------------------------------------------
-// Encoder state of one packet (arCompress :487-531).
-// ---------------------------------------------------------------------------
-template <uint32_t kStride>
-struct EncoderLane {
-    ModelTree<kStride> model;
-    BitSink sink;
-    uint32_t lo, hi, pending;
-
-    GPUAR_LANE void open(uint16_t *col, uint8_t *slot) {
-        model.col = col;
-        model.reset();
-        sink.open(slot + kHdr);
-        lo = 0;             // :492-494
-        hi = 0xFFFFu;
-        pending = 0;
-    }
-
-    // symbol number i of the packet (model total = 256 + i), rc = reciprocal of that total
-    GPUAR_LANE void step(uint32_t x, uint32_t i, Recip rc) {
-        const uint32_t cums = model.encode_step(x, 256u + i);
-        narrow(lo, hi, cums & 0xFFFFu, cums >> 16, rc);
-        const uint32_t hi_before = hi;
-        const Renorm r = renorm_split(lo, hi);
-        if (r.e) {
-            // agreed MSB b, then `pending` copies of !b, then the other e-1 agreed bits
-            const uint32_t agreed = hi_before >> (16u - r.e);
-            const uint32_t b_top = agreed >> (r.e - 1u);
-            const uint32_t rest = agreed & ((1u << (r.e - 1u)) - 1u);
-            if (pending <= 16u) {
-                const uint32_t run = b_top ? (1u << pending) : ((1u << pending) - 1u);
-                sink.put((run << (r.e - 1u)) | rest, r.e + pending);
-            } else {
-                sink.put(b_top, 1u);
-                sink.put_run(b_top ^ 1u, pending);
-                if (r.e > 1u) sink.put(rest, r.e - 1u);
-            }
-            pending = 0;
-        }
-        pending += r.u;
-    }
-
-    // flush (writeRemaining :379-388, writeClose :430-439) and write the
-    // packet header (:525-528); returns clen, sets `overflowed` when the
-    // packet did not fit its slot (its stored length is then clamped).
-    GPUAR_LANE uint32_t finish(uint8_t *slot, uint32_t ulen, bool &overflowed) {
-        const uint32_t b = (lo >> 14) & 1u;
-        sink.put(b, 1u);
-        sink.put_run(b ^ 1u, pending + 1u);
-        uint32_t clen = sink.close() + kHdr;
-        overflowed = sink.overflow || clen > kSlot;
-        if (overflowed) clen = kSlot;
-        const uint32_t hdr = clen | (ulen << 16);   // u16 LE clen, u16 LE ulen
-        memcpy(slot, &hdr, 4);
-        return clen;
-    }
-};
-
 // ===========================================================================
-// Split encoder: the model walk and the range coder as two separate lane
-// programs, joined by one 32-bit word per symbol (cumLo | cumHi << 16).  On the
-// GPU they run in two different wavefronts of a workgroup (a "modeler" and a
-// "coder" wave serving the same 64 packets through an LDS ring), so that every
-// SIMD holds two wavefronts although a packet's model pins 32 KiB of LDS per
-// 64 packets.  Same arithmetic as EncoderLane above, re-expressed to cost
-// fewer vector instructions.
+// ENCODER.  The per-symbol work of arCompress (:487-531) as three lane
+// programs -- two partial modelers and a coder -- joined by 32-bit words
+// (their sum per symbol is cumLo | cumHi << 16).  On the GPU they run in three
+// wavefronts of a workgroup serving the same 64 packets through an LDS ring;
+// on the host (tests, --host) one thread simply calls them in turn.
+//
+// Model = complete binary tree over the 256 symbols, each node holding the
+// count of symbols in its LEFT subtree (u16).  For a symbol x the eight nodes
+// on its path give cumLo = sum of the nodes where the path turns right, the
+// same sum for x + 1 gives cumHi (the path of x + 1 leaves the path of x at
+// x's lowest zero bit and has only zero bits below, so it can be taken over
+// x's own nodes), and adding 1 to the nodes where the path turns left counts
+// x.  Exactly the reference's counts (Fenwick getRange/update :215-238 and the
+// all-ones start :403-419), in a container that needs one walk for all three.
 // ===========================================================================
 
-// Model tree in IN-ORDER layout: the node at depth k on the path of symbol x
+// Node addressing, IN-ORDER layout: the node at depth k on the path of symbol x
 // sits in row (x & topmask_k) | ((1 << (7-k)) - 1), so its address is one
 // AND-OR of the pre-shifted symbol plus a compile-time offset.  kRowShift =
-// log2(bytes between rows): 7 on the GPU (64 lanes x u16), 1 on the host.
+// log2(bytes between rows): 7 on the GPU (64 lanes x u16, lane-minor, so lane
+// l always hits LDS bank l & 31), 1 on the host.
 template <uint32_t kRowShift>
 struct InorderModel {
     uint8_t *col;   // this lane's column: row r lives at col + (r << kRowShift)
@@ -372,100 +185,18 @@ struct InorderModel {
         const uint32_t fixed = ((1u << (7 - k)) - 1u) << kRowShift;
         return reinterpret_cast<uint16_t *>(col + ((x_shifted & keep) | fixed));
     }
-
-    GPUAR_LANE void reset() {
-#pragma unroll 1
-        for (uint32_t row = 0; row < 255u; ++row) {
-            // row r is a node of depth 7 - (number of trailing ones of r)
-            const uint32_t trailing_ones = 31u - GPUAR_CLZ32((row ^ (row + 1u)));
-            *reinterpret_cast<uint16_t *>(col + (row << kRowShift)) = static_cast<uint16_t>(1u << trailing_ones);
-        }
-    }
-
-    // returns cumLo | cumHi << 16 for symbol x (model total = `total`) and counts x
-    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total) {
-        const uint32_t xs = x << kRowShift;
-        // bit j of the low half = bit j of x, of the high half = bit j of x + 1
-        const uint32_t z = x * 0x10001u + 0x10000u;
-        uint32_t left[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) left[k] = *node(xs, k);
-        uint32_t acc = ((z >> 8) & 0x10001u) * total;       // x == 255: cumHi is the whole total
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t pick = (z >> (7 - k)) & 0x10001u;  // low: path goes right at depth k; high: same for x+1
-            acc += left[k] * pick;
-            *node(xs, k) = static_cast<uint16_t>((pick ^ 1u) + left[k]);   // +1 where x goes left
-        }
-        return acc;
-    }
 };
 
-// The modeler as the kernel runs it: same tree, but
-//  * depths 0 and 1 (three nodes) live in registers, depths 2..7 in LDS rows
-//    (an LDS operation costs the CU more than the few selects that replace it);
-//  * software-pipelined: while symbol i is being accounted, the six LDS
-//    nodes of symbol i+1 are already being fetched.  Each fetch is issued
-//    right AFTER the store to the same depth for symbol i, and LDS operations
-//    of a wavefront complete in order, so a node shared by both symbols is
-//    read with symbol i's increment already applied.  The six node addresses
-//    travel with the prefetched values, so each is computed once per symbol.
-template <uint32_t kRowShift>
-struct ModelerLane {
-    InorderModel<kRowShift> tree;
-    uint32_t root;                          // depth 0
-    uint32_t half0, half1;                  // depth 1: under the root's left / right child
-    uint32_t left[6];                       // depths 2..7 of the NEXT symbol to account
-    uint16_t *where[6];                     // ... and where they live
-
-    GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
-        tree.col = col;
-        tree.reset();
-        root = 128u;
-        half0 = half1 = 64u;
-        const uint32_t xs = first_symbol << kRowShift;
-#pragma unroll
-        for (int k = 2; k < 8; ++k) {
-            where[k - 2] = tree.node(xs, k);
-            left[k - 2] = *where[k - 2];
-        }
-    }
-
-    // accounts symbol x (model total `total`), prefetches for x_next;
-    // returns cumLo | cumHi << 16
-    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
-        const uint32_t xn = x_next << kRowShift;
-        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
-        uint32_t acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);   // x == 255: cumHi is the whole total
-        const uint32_t pick0 = (z >> 7) & 0x10001u;
-        acc += GPUAR_MUL24(root, pick0);
-        root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
-        // depth 1 in registers: two LDS operations fewer per symbol
-        const bool upper_half = x >= 128u;
-        const uint32_t pick1 = (z >> 6) & 0x10001u;
-        acc += GPUAR_MUL24(upper_half ? half1 : half0, pick1);
-        const uint32_t quarter = x >> 6;
-        half0 += quarter == 0u ? 1u : 0u;
-        half1 += quarter == 2u ? 1u : 0u;
-#pragma unroll
-        for (int k = 2; k < 8; ++k) {
-            const uint32_t pick = (z >> (7 - k)) & 0x10001u;      // low: x goes right at depth k; high: same for x+1
-            const uint32_t l = left[k - 2];
-            acc += GPUAR_MUL24(l, pick);
-            *where[k - 2] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
-            where[k - 2] = tree.node(xn, k);
-            left[k - 2] = *where[k - 2];
-        }
-        return acc;
-    }
-};
-
-// The modeler split in two, for the three-wavefront encoder: one lane program
-// owns depths [kFirst, kFirst + kDepths) of the tree (its rows of the shared LDS
-// table are disjoint from the other's), optionally the register-resident
-// depths 0 and 1 (kHead) and the x == 255 term (kTail).  Each returns its part
-// of cumLo | cumHi << 16; the parts add up to ModelerLane::step()'s value
-// (both halves stay below 2^16, so the packed add cannot carry across).
+// One partial modeler owns depths [kFirst, kFirst + kDepths) of the tree (its
+// rows of the shared table are disjoint from the other's), optionally the
+// register-resident depths 0 and 1 (kHead) and the x == 255 term (kTail), and
+// returns its part of cumLo | cumHi << 16 (both halves stay below 2^16, so the
+// packed add of the parts cannot carry across).  Software-pipelined: while
+// symbol i is being accounted, this part's nodes of symbol i+1 are already
+// being fetched -- each fetch is issued right AFTER the store to the same depth
+// for symbol i, and LDS operations of a wavefront complete in order, so a node
+// shared by both symbols is read with symbol i's increment applied.  The node
+// addresses travel with the prefetched values.
 template <uint32_t kRowShift, int kFirst, int kDepths, bool kHead, bool kTail>
 struct PartialModeler {
     InorderModel<kRowShift> tree;
@@ -644,139 +375,10 @@ struct CoderLane {
     }
 };
 
-// ---------------------------------------------------------------------------
-// Bit source for the decoder (readBit/getChar :533-569).  Aligned dwords are
-// fetched one ahead; reads never leave [.., limit).
-// ---------------------------------------------------------------------------
-struct BitSource {
-    uint64_t win;        // next bits, left-aligned
-    uint32_t n;          // valid bits in win
-    uint32_t ahead;      // next dword, already byte-swapped
-    const uint8_t *next; // address of the dword after `ahead` (4-byte aligned)
-    const uint8_t *limit;
-
-    GPUAR_LANE uint32_t fetch() {
-        uint32_t w = 0;
-        if (next + 4 <= limit) {
-            memcpy(&w, next, 4);
-            w = bswap32(w);
-        } else {
-            for (int b = 0; b < 4; ++b)
-                if (next + b < limit) w |= static_cast<uint32_t>(next[b]) << (24 - 8 * b);
-        }
-        next += 4;
-        return w;
-    }
-    GPUAR_LANE void refill() {
-        if (n <= 32u) {
-            win |= static_cast<uint64_t>(ahead) << (32u - n);
-            n += 32u;
-            ahead = fetch();
-        }
-    }
-    GPUAR_LANE uint32_t take(uint32_t count) {  // count <= 31, n >= count
-        const uint32_t v = static_cast<uint32_t>((win >> 1) >> (63u - count));
-        win <<= count;
-        n -= count;
-        return v;
-    }
-    // `body` may sit at any byte address: fetch aligned dwords from the one
-    // containing it and drop the leading bytes (the packet's own header, or
-    // the tail of the previous packet in the same allocation).
-    GPUAR_LANE void open(const uint8_t *body, const uint8_t *lim) {
-        const uint32_t skip = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(body) & 3u);
-        next = body - skip;
-        limit = lim;
-        win = static_cast<uint64_t>(fetch()) << 32;
-        n = 32;
-        ahead = fetch();
-        if (skip) {
-            take(8u * skip);
-            refill();
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------
-// Decoder state of one packet (arDecompress :848-892).
-// ---------------------------------------------------------------------------
-template <uint32_t kStride>
-struct DecoderLane {
-    ModelTree<kStride> model;
-    BitSource bits;
-    uint32_t lo, hi, code;
-    uint32_t ulen;       // symbols this lane still has to produce in total
-    uint32_t outword;
-    bool bad;
-
-    // pkt -> 4-byte packet header; bytes in [pkt, limit) are readable.  A lane
-    // without a packet passes live = false and does nothing afterwards.
-    GPUAR_LANE void open(uint16_t *col, const uint8_t *pkt, const uint8_t *limit, bool live) {
-        model.col = col;
-        model.reset();
-        ulen = 0;
-        bad = false;
-        outword = 0;
-        if (live) {
-            const uint32_t clen = pkt[0] | (static_cast<uint32_t>(pkt[1]) << 8);
-            ulen = pkt[2] | (static_cast<uint32_t>(pkt[3]) << 8);
-            if (ulen > kPacket || clen < kHdr) {   // the reference would run off its buffers here
-                bad = true;
-                ulen = 0;
-            }
-        }
-        bits.open(live ? pkt + kHdr : pkt, live ? limit : pkt);
-        lo = 0;
-        hi = 0xFFFFu;
-        code = bits.take(16);   // initializeDecoder :582-603
-    }
-
-    // produce symbol i (call only while i < ulen); `out` is the packet's
-    // 4-byte-aligned output base
-    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
-        const uint32_t total = 256u + i;
-        bits.refill();
-        // getUnscaledCode :703-716 -- the divisor (range) differs per lane:
-        // reciprocal estimate, then an exact integer correction (the estimate is
-        // within 1 of the quotient: q < 2^14, relative error < 2^-21)
-        const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-        const uint32_t num = (((code - lo) & 0xFFFFu) + 1u) * total - 1u;
-        uint32_t q = GPUAR_RCP_QUOT(num, range);
-        int32_t rem = static_cast<int32_t>(num - q * range);
-        if (rem < 0) {
-            --q;
-            rem += static_cast<int32_t>(range);
-        }
-        if (rem >= static_cast<int32_t>(range)) ++q;
-        if (q >= total) {        // no symbol owns this code value (:873-877): stop this lane
-            bad = true;
-            ulen = i;
-            return;
-        }
-        uint32_t cum_lo, cum_hi;
-        const uint32_t sym = model.decode_step(q, total, cum_lo, cum_hi);
-        outword |= sym << (8u * (i & 3u));
-        if ((i & 3u) == 3u) {
-            memcpy(out + (i & ~3u), &outword, 4);
-            outword = 0;
-        }
-        narrow(lo, hi, cum_lo, cum_hi, rc);
-        const Renorm r = renorm_split(lo, hi);
-        // e agree-shifts pull e bits into code; every underflow shift is
-        // `code ^= 0x4000` then a shift, i.e. bit 14 dropped and the MSB kept
-        code = ((code << r.e) | bits.take(r.e)) & 0xFFFFu;
-        if (r.u) code = (((code << r.u) ^ 0x8000u) | bits.take(r.u)) & 0xFFFFu;
-    }
-
-    // bytes of a packet whose length is not a multiple of 4
-    GPUAR_LANE void finish(uint8_t *out) {
-        for (uint32_t b = ulen & ~3u; b < ulen; ++b) out[b] = static_cast<uint8_t>(outword >> (8u * (b & 3u)));
-    }
-};
-
 // ===========================================================================
-// Decoder, second form: the symbol search touches LDS in two round trips
-// instead of eight, with one 16-byte read each.  Depths 0 and 1 of the
+// DECODER (arDecompress :848-892).  The symbol search
+// (getSymbolFromProbability :727-763) touches LDS in two round trips of one
+// 16-byte read each instead of walking eight levels.  Depths 0 and 1 of the
 // left-count tree live in registers; depths 2..4 and 5..7 are stored as
 // 3-level subtrees, each one 16-byte RECORD of eight u16
 //     [a | b0 b1 | c0 c1 c2 c3 | pad]
@@ -784,8 +386,8 @@ struct DecoderLane {
 // need, and those decisions are then taken in registers.  (Measured with
 // tools/lds_probe.hip: at these occupancies a u16 LDS read costs the CU about
 // as much as a 16-byte one, and the seven separate u16 reads per subtree were
-// what bounded the previous form of this kernel.)  Same counts, same sums,
-// same symbols as ModelTree::decode_step.
+// what bounded the previous form of this kernel.)  Same left-count tree as
+// the encoder's, same counts, same sums, same symbols.
 //   records  0..3   : subtrees rooted at the depth-2 nodes (index = top 2 bits)
 //   records  4..35  : subtrees rooted at the depth-5 nodes (index = top 5 bits)
 // kRecShift = log2(bytes between consecutive records of one lane): 10 on the
@@ -805,7 +407,7 @@ struct SubtreeModel {
     uint32_t root, half0, half1;        // depth 0; depth 1 under root's left / right child
     Path owed;                          // write-back of the previous symbol's low record, not yet issued
 
-    static constexpr uint32_t kRecords = 36;
+    static constexpr uint32_t kRecords = kDecodeRecords;
 
     GPUAR_LANE void reset() {
         root = 128u;
@@ -918,11 +520,11 @@ struct SubtreeModel {
     GPUAR_LANE void flush() { write_back(owed); }
 };
 
-// Decoder lane built on SubtreeModel, with a leaner bit reader: two aligned
+// Decoder state of one packet: SubtreeModel plus a bit reader of two aligned
 // big-endian dwords (w0:w1) hold the stream at the current position, a third
 // is in flight; one funnel shift per symbol exposes the next 32 bits.
 template <uint32_t kRowShift>
-struct DecoderLane2 {
+struct DecoderLane {
     SubtreeModel<kRowShift> model;
     uint32_t w0, w1;           // two consecutive stream dwords, big-endian order restored
     uint32_t ahead;            // the dword after w1, still as loaded (swapped only when it moves up,

@@ -15,64 +15,20 @@ static const RecipTable kRecip = RecipTable();
 
 extern "C" {
 
+// What the three encoder wavefronts do (TopModeler + LowModeler + CoderLane), packet by packet.
 // slots: ceil(n/8192) * 8704 bytes.  Returns the OR of per-packet overflow flags.
 int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 {
     int any_overflow = 0;
     const size_t np = (n_bytes + kPacket - 1) / kPacket;
-    std::vector<uint16_t> tree(kTreeRows);
-    for (size_t p = 0; p < np; ++p) {
-        const size_t off = p * kPacket;
-        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
-        uint8_t *slot = slots + p * kSlot;
-        EncoderLane<1> enc;
-        enc.open(tree.data(), slot);
-        for (uint32_t i = 0; i < len; ++i) enc.step(in[off + i], i, kRecip.r[i]);
-        bool ov;
-        enc.finish(slot, len, ov);
-        any_overflow |= ov ? 1 : 0;
-    }
-    return any_overflow;
-}
-
-// The split (modeler + coder) encoder the wave-specialised kernel runs.
-int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
-{
-    int any_overflow = 0;
-    const size_t np = (n_bytes + kPacket - 1) / kPacket;
-    std::vector<uint16_t> tree(256);
-    for (size_t p = 0; p < np; ++p) {
-        const size_t off = p * kPacket;
-        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
-        uint8_t *slot = slots + p * kSlot;
-        ModelerLane<1> model;
-        model.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
-        CoderLane coder;
-        coder.open(slots, static_cast<uint32_t>(p * kSlot));
-        for (uint32_t i = 0; i < len; ++i) {
-            const uint32_t next = i + 1 < len ? in[off + i + 1] : 0u;
-            coder.step(model.step(in[off + i], 256u + i, next), kRecip.r[i]);
-        }
-        bool ov;
-        coder.finish(len, ov);
-        any_overflow |= ov ? 1 : 0;
-    }
-    return any_overflow;
-}
-
-// The three-wavefront split (TopModeler + LowModeler + CoderLane).
-int emu_encode_slots_split3(const uint8_t *in, size_t n_bytes, uint8_t *slots)
-{
-    int any_overflow = 0;
-    const size_t np = (n_bytes + kPacket - 1) / kPacket;
-    std::vector<uint16_t> tree(256);
+    std::vector<uint16_t> table(kTreeRows);
     for (size_t p = 0; p < np; ++p) {
         const size_t off = p * kPacket;
         const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
         TopModeler<1> top;
         LowModeler<1> low;
-        top.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
-        low.open(reinterpret_cast<uint8_t *>(tree.data()), in[off]);
+        top.open(reinterpret_cast<uint8_t *>(table.data()), in[off]);
+        low.open(reinterpret_cast<uint8_t *>(table.data()), in[off]);
         CoderLane coder;
         coder.open(slots, static_cast<uint32_t>(p * kSlot));
         for (uint32_t i = 0; i < len; ++i) {
@@ -87,34 +43,18 @@ int emu_encode_slots_split3(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     return any_overflow;
 }
 
+// What a decoder wavefront's lane does (SubtreeModel + DecoderLane).
 // pkt_offsets: np+1 byte offsets into `stream`; out: np * 8192 bytes.
 // Returns the number of packets flagged bad.
 int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)
 {
     int bad = 0;
-    std::vector<uint16_t> tree(kTreeRows);
+    std::vector<uint64_t> records(kDecodeRecords * 2);       // 16 bytes each, 8-byte aligned storage
     const uint8_t *limit = stream + pkt_offsets[np];
     for (size_t p = 0; p < np; ++p) {
-        DecoderLane<1> dec;
+        DecoderLane<4> dec;
         uint8_t *o = out + p * kPacket;
-        dec.open(tree.data(), stream + pkt_offsets[p], limit, true);
-        for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
-        dec.finish(o);
-        bad += dec.bad ? 1 : 0;
-    }
-    return bad;
-}
-
-// Second decoder form (SubtreeModel + DecoderLane2): what the decode kernels run.
-int emu_decode_stream2(const uint8_t *stream, const uint64_t *pkt_offsets, size_t np, uint8_t *out)
-{
-    int bad = 0;
-    std::vector<uint16_t> tree(36 * 8);
-    const uint8_t *limit = stream + pkt_offsets[np];
-    for (size_t p = 0; p < np; ++p) {
-        DecoderLane2<4> dec;
-        uint8_t *o = out + p * kPacket;
-        dec.open(reinterpret_cast<uint8_t *>(tree.data()), stream + pkt_offsets[p], limit, true);
+        dec.open(reinterpret_cast<uint8_t *>(records.data()), stream + pkt_offsets[p], limit, true);
         for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
         dec.finish(o);
         bad += dec.bad ? 1 : 0;

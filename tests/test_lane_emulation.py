@@ -2,8 +2,9 @@
 
 The header is compiled for the host (g++) into a small test-only library and
 driven one packet at a time; outputs must equal the oracle's byte for byte on
-every golden fixture.  This is how the closed-form renormalisation, the
-left-count tree and the reciprocal division are validated where there is no
+every golden fixture.  This is how the left-count tree, the partial modelers,
+the closed-form renormalisation, the bit-field-mask emission, the reciprocal
+division and the division-free symbol search are validated where there is no
 GPU; the GPU parity tests (tests/test_gpu_parity.py) then check the real kernels.
 """
 import ctypes as C
@@ -28,30 +29,24 @@ def emu():
     so = os.path.join(out_dir, "liblane_emulation.so")
     srcs = [os.path.join(HERE, "lane_emulation.cpp"), os.path.join(ROOT, "gpuar_amd", "csrc", "lane_codec.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000", "-DGPUAR_LANE_TEST_PERTURB",
-                               "-fconstexpr-loop-limit=1000000", "-I", os.path.join(ROOT, "include"), "-o", so, srcs[0]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000",
+                               "-fconstexpr-loop-limit=1000000", "-Wno-unknown-pragmas",
+                               "-I", os.path.join(ROOT, "include"), "-o", so, srcs[0]])
     lib = C.CDLL(so)
     lib.emu_encode_slots.restype = C.c_int
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
-    lib.emu_encode_slots_split.restype = C.c_int
-    lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
-    lib.emu_encode_slots_split3.restype = C.c_int
-    lib.emu_encode_slots_split3.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
-    lib.emu_decode_stream2.restype = C.c_int
-    lib.emu_decode_stream2.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
     lib.emu_check_recip.argtypes = [C.c_uint32]
     return lib
 
 
-def emu_encode(lib, data: np.ndarray, split=False):
+def emu_encode(lib, data: np.ndarray):
     npk = (data.size + 8191) // 8192
     slots = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
     src = np.ascontiguousarray(data)
-    fn = {False: lib.emu_encode_slots, True: lib.emu_encode_slots_split, 3: lib.emu_encode_slots_split3}[split]
-    ov = fn(src.ctypes.data_as(u8p), src.size, slots.ctypes.data_as(u8p))
+    ov = lib.emu_encode_slots(src.ctypes.data_as(u8p), src.size, slots.ctypes.data_as(u8p))
     return slots, npk, ov
 
 
@@ -65,30 +60,16 @@ def slots_to_stream(slots, npk):
     return stream, np.asarray(offs, dtype=np.uint64)
 
 
-def emu_decode(lib, stream, offs, npk, form=1):
+def emu_decode(lib, stream, offs, npk):
     padded = np.concatenate([stream, np.zeros(16, dtype=np.uint8)])
     out = np.zeros(max(npk, 1) * 8192, dtype=np.uint8)
-    fn = lib.emu_decode_stream if form == 1 else lib.emu_decode_stream2
-    bad = fn(padded.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), npk, out.ctypes.data_as(u8p))
+    bad = lib.emu_decode_stream(padded.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), npk, out.ctypes.data_as(u8p))
     return out, bad
 
 
 def test_reciprocal_table_is_exact(emu):
     # every total, every 97th multiple boundary on both sides, plus the extremes
     assert emu.emu_check_recip(97) == 0
-
-
-@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
-def test_split_encoder_matches_reference_fixture(emu, port_oracle, c):
-    """InorderModel + CoderLane: what the modeler / coder wavefronts of the encode kernel run."""
-    data = case_input(c)
-    want = port_oracle.encode_stream(data)
-    for split in (True, 3):       # two-part (modeler + coder) and three-part (top + low modeler + coder) forms
-        slots, npk, ov = emu_encode(emu, data, split=split)
-        assert ov == 0
-        stream, _ = slots_to_stream(slots, npk)
-        assert stream.size == c["stream_len"]
-        assert np.array_equal(stream, want)
 
 
 @pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
@@ -103,14 +84,11 @@ def test_lane_codec_matches_reference_fixture(emu, port_oracle, c):
     out, bad = emu_decode(emu, stream, offs, npk)
     assert bad == 0
     assert np.array_equal(out[:data.size], data)
-    out2, bad2 = emu_decode(emu, stream, offs, npk, form=2)      # SubtreeModel + DecoderLane2
-    assert bad2 == 0
-    assert np.array_equal(out2[:data.size], data)
 
 
 def test_lane_codec_random_packets(emu, port_oracle):
     rng = np.random.default_rng(7)
-    for trial in range(40):
+    for trial in range(60):
         n = int(rng.integers(1, 3 * 8192))
         if trial % 3 == 0:
             data = rng.integers(0, 256, n, dtype=np.uint8)
@@ -121,26 +99,21 @@ def test_lane_codec_random_packets(emu, port_oracle):
         slots, npk, ov = emu_encode(emu, data)
         stream, offs = slots_to_stream(slots, npk)
         assert ov == 0 and np.array_equal(stream, port_oracle.encode_stream(data)), trial
-        for split in (True, 3):
-            slots2, _, ov2 = emu_encode(emu, data, split=split)
-            assert ov2 == 0 and np.array_equal(slots2, slots), (trial, split)
         out, bad = emu_decode(emu, stream, offs, npk)
         assert bad == 0 and np.array_equal(out[:n], data), trial
-        out2, bad2 = emu_decode(emu, stream, offs, npk, form=2)
-        assert bad2 == 0 and np.array_equal(out2[:n], data), trial
 
 
 def test_lane_decoder_survives_garbage(emu):
     """Malformed packets must neither crash nor write outside their 8192-byte output."""
     rng = np.random.default_rng(11)
-    for trial in range(20):
+    flagged = 0
+    for trial in range(40):
         blob = rng.integers(0, 256, 9000, dtype=np.uint8)
         blob[0:2] = np.frombuffer(int(9000 - 16).to_bytes(2, "little"), dtype=np.uint8)
         blob[2:4] = np.frombuffer(int(rng.integers(0, 65536)).to_bytes(2, "little"), dtype=np.uint8)
         offs = np.asarray([0, 9000 - 16], dtype=np.uint64)
         out = np.zeros(8192 + 64, dtype=np.uint8)
         out[8192:] = 0xA5
-        emu.emu_decode_stream(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
+        flagged += emu.emu_decode_stream(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
         assert np.all(out[8192:] == 0xA5)
-        emu.emu_decode_stream2(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
-        assert np.all(out[8192:] == 0xA5)
+    assert flagged > 0          # impossible lengths and out-of-model code values are reported
