@@ -486,7 +486,11 @@ struct SubtreeModel {
     //   after this write) -> read low record -> write back the mid record ->
     //   (low record's write-back is owed to the next call / flush()).
     // Each write-back thus sits in the shadow of a read instead of in front of it.
-    GPUAR_LANE uint32_t decode_step(uint32_t num, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi) {
+    // `in_shadow()` is called right after the first record read has been issued:
+    // work that the symbol search does not depend on goes there.
+    template <typename Shadow>
+    GPUAR_LANE uint32_t decode_step(uint32_t num, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi,
+                                    Shadow &&in_shadow) {
         const bool l0 = num < GPUAR_MUL24_VV(root, range);
         uint32_t below = l0 ? 0u : root;
         uint32_t upper = l0 ? root : total;
@@ -500,6 +504,7 @@ struct SubtreeModel {
         Quad q_mid = load128(rec_mid);                        // ds_read_b128 #1 ...
         GPUAR_PIN_LOAD(q_mid);
         write_back(owed);                                     // ... with the previous symbol's write-back behind it
+        in_shadow();
         root += l0 ? 1u : 0u;                                 // register nodes: also in the shadow of read #1
         half0 += (l0 && l1) ? 1u : 0u;
         half1 += (!l0 && l1) ? 1u : 0u;
@@ -530,6 +535,8 @@ struct DecoderLane {
     uint32_t ahead;            // the dword after w1, still as loaded (swapped only when it moves up,
                                // so the wait for its load lands a whole dword of bits later)
     uint32_t bit;              // bits of w0 already consumed (0..31)
+    uint32_t owed_bits;        // bits consumed by the previous symbol, not yet skipped (done in the
+                               // shadow of the next symbol's first record read)
     const uint8_t *next;       // address of the dword after `ahead` (4-byte aligned)
     const uint8_t *limit;
     uint32_t lo, hi, code;
@@ -590,6 +597,7 @@ struct DecoderLane {
         hi = 0xFFFFu;
         code = peek() >> 16;    // initializeDecoder :582-603
         skip(16u);
+        owed_bits = 0;
     }
 
     // decodes symbol i and returns it; the caller places it (see put_symbol / flush)
@@ -603,7 +611,9 @@ struct DecoderLane {
         // the output inside its 8192 bytes whatever the bits are.
         bad = bad || num >= GPUAR_MUL24(range, total);
         uint32_t cum_lo, cum_hi;
-        const uint32_t sym = model.decode_step(num, range, total, cum_lo, cum_hi);
+        const uint32_t sym = model.decode_step(num, range, total, cum_lo, cum_hi, [this]() {
+            skip(owed_bits);          // the stream window is next needed at the end of this symbol
+        });
         narrow(lo, hi, cum_lo, cum_hi, rc);
         const Renorm r = renorm_split(lo, hi);
         // e agree-shifts and u underflow-shifts pull e + u (<= 31) fresh bits in
@@ -613,7 +623,7 @@ struct DecoderLane {
         const uint32_t n = r.e + r.u;
         const uint32_t fresh = (peek() >> 1) >> (31u - n);
         code = (((code << n) | fresh) ^ (r.u ? 0x8000u : 0u)) & 0xFFFFu;
-        skip(n);
+        owed_bits = n;
         return sym;
     }
 
