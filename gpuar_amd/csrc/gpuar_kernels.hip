@@ -100,7 +100,7 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
     uint4 cur = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
     uint4 nxt = len > 16u ? load16_guarded(in + 16, len - 16u) : make_uint4(0, 0, 0, 0);
     Model model;
-    model.open(lds.tree + 2u * lane_column(lane), cur.x & 0xFFu);
+    model.open(lds.tree, 2u * lane_column(lane), cur.x & 0xFFu);
     for (uint32_t k = 0; k <= n_phases; ++k) {
         if (k < n_phases) {
             const uint32_t base = k * kPhase;

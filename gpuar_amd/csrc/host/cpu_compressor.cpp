@@ -25,8 +25,8 @@ size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
     uint8_t *col = reinterpret_cast<uint8_t *>(table);
     gpuar::TopModeler<1> top;
     gpuar::LowModeler<1> low;
-    top.open(col, in[0]);
-    low.open(col, in[0]);
+    top.open(col, 0, in[0]);
+    low.open(col, 0, in[0]);
     gpuar::CoderLane coder;
     coder.open(slot, 0);
     for (uint32_t i = 0; i < len; ++i) {

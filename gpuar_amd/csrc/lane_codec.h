@@ -178,12 +178,17 @@ GPUAR_LANE void store32(uint8_t *at, uint32_t v) {
 // l always hits LDS bank l & 31), 1 on the host.
 template <uint32_t kRowShift>
 struct InorderModel {
-    uint8_t *col;   // this lane's column: row r lives at col + (r << kRowShift)
+    uint8_t *table;      // first byte of the node table (same pointer in every lane of a wavefront)
+    uint32_t lane_bits;  // this lane's byte offset inside a row (< 1 << kRowShift)
 
-    GPUAR_LANE uint16_t *node(uint32_t x_shifted, int k) const {
-        const uint32_t keep = ((0xFF00u >> k) & 0xFFu) << kRowShift;     // top k bits of the symbol
+    // x_tag = (x << kRowShift) | lane_bits, formed once per symbol; the node
+    // address is then ONE two-operand AND (a full-rate instruction) plus a
+    // compile-time offset the LDS instruction carries as an immediate.
+    GPUAR_LANE uint32_t tag(uint32_t x) const { return (x << kRowShift) | lane_bits; }
+    GPUAR_LANE uint16_t *node(uint32_t x_tag, int k) const {
+        const uint32_t keep = (((0xFF00u >> k) & 0xFFu) << kRowShift) | ((1u << kRowShift) - 1u);
         const uint32_t fixed = ((1u << (7 - k)) - 1u) << kRowShift;
-        return reinterpret_cast<uint16_t *>(col + ((x_shifted & keep) | fixed));
+        return reinterpret_cast<uint16_t *>(table + (x_tag & keep) + fixed);
     }
 };
 
@@ -204,19 +209,21 @@ struct PartialModeler {
     uint32_t left[kDepths];                 // this part's nodes of the NEXT symbol to account
     uint16_t *where[kDepths];
 
-    GPUAR_LANE void open(uint8_t *col, uint32_t first_symbol) {
-        tree.col = col;
+    // table: first byte of the shared node table; lane_bits: this lane's byte offset inside a row
+    GPUAR_LANE void open(uint8_t *table, uint32_t lane_bits, uint32_t first_symbol) {
+        tree.table = table;
+        tree.lane_bits = lane_bits;
         // initial counts, own rows only (the other part initialises its own)
 #pragma unroll 1
         for (uint32_t row = 0; row < 255u; ++row) {
             const uint32_t trailing_ones = 31u - GPUAR_CLZ32((row ^ (row + 1u)));
             const int depth = 7 - static_cast<int>(trailing_ones);
             if (depth >= kFirst && depth < kFirst + kDepths)
-                *reinterpret_cast<uint16_t *>(col + (row << kRowShift)) = static_cast<uint16_t>(1u << trailing_ones);
+                *reinterpret_cast<uint16_t *>(table + (row << kRowShift) + lane_bits) = static_cast<uint16_t>(1u << trailing_ones);
         }
         root = 128u;
         half0 = half1 = 64u;
-        const uint32_t xs = first_symbol << kRowShift;
+        const uint32_t xs = tree.tag(first_symbol);
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
             where[k] = tree.node(xs, kFirst + k);
@@ -225,7 +232,7 @@ struct PartialModeler {
     }
 
     GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
-        const uint32_t xn = x_next << kRowShift;
+        const uint32_t xn = tree.tag(x_next);
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
         uint32_t acc = 0;
         if (kTail) acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);  // x == 255: cumHi is the whole total

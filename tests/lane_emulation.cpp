@@ -27,8 +27,8 @@ int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
         TopModeler<1> top;
         LowModeler<1> low;
-        top.open(reinterpret_cast<uint8_t *>(table.data()), in[off]);
-        low.open(reinterpret_cast<uint8_t *>(table.data()), in[off]);
+        top.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
+        low.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
         CoderLane coder;
         coder.open(slots, static_cast<uint32_t>(p * kSlot));
         for (uint32_t i = 0; i < len; ++i) {
