@@ -28,6 +28,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this pool (already exported there; harmless to repeat)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 GIB = 1 << 30
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
