@@ -130,14 +130,17 @@ void GPUCompressor::releaseBuffers() {
     buffers.clear();
 }
 
+// two buffer sets per device: while the GPUs work on one round, the host reads
+// the next round's input into the other set and writes the previous round's output
 void GPUCompressor::ensureBuffers() {
-    if (buffers.size() == devices.size() && !buffers.empty() && buffers[0]->cap == batchPackets) return;
+    if (buffers.size() == 2 * devices.size() && !buffers.empty() && buffers[0]->cap == batchPackets) return;
     releaseBuffers();
-    for (int dev : devices) {
-        DeviceBuffers *b = new DeviceBuffers();
-        buffers.push_back(b);
-        b->allocate(dev, batchPackets);
-    }
+    for (int set = 0; set < 2; ++set)
+        for (int dev : devices) {
+            DeviceBuffers *b = new DeviceBuffers();
+            buffers.push_back(b);
+            b->allocate(dev, batchPackets);
+        }
 }
 
 void GPUCompressor::chooseDevice(const int id) {
@@ -158,10 +161,22 @@ void GPUCompressor::useDevices(const int n) {
 }
 
 namespace {
-template <typename F>
-void run_on_each(std::vector<GPUCompressor *> &, F &&) {}
+
+// One round in flight: the device work of every GPU on one buffer set, each on its own host thread.
+struct Round {
+    std::vector<std::thread> workers;
+    bool active = false;
+    void join() {
+        for (auto &w : workers) w.join();
+        workers.clear();
+    }
+};
+
 }  // namespace
 
+// Pipeline over rounds r = 0, 1, ... with buffer set r & 1:
+//   read input of round r  ||  GPUs run round r-1   (then)   GPUs run round r  ||  write output of round r-1
+// File order is kept because rounds, and devices within a round, are drained in order.
 CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     CompressionInfo info;
     monitor->reset();
@@ -170,38 +185,19 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     io_timer.start();
     openFiles();
     double kernel_ms_total = 0;
+    Round in_flight;
     try {
         ensureBuffers();
         info.uncompressedFileSize = getFileSize(openFile);
         if (std::fseek(saveFile, FileHeader::HEADER_LENGTH, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
         info.compressedFileSize = FileHeader::HEADER_LENGTH;
-        const size_t G = buffers.size();
+        const size_t G = devices.size();
         size_t remaining = info.uncompressedFileSize;
-        while (remaining > 0) {
-            // contiguous packet ranges, device order = file order (SURVEY.md section 8(e))
-            const size_t round_bytes = std::min(remaining, G * batchPackets * kPacket);
-            const size_t round_packets = (round_bytes + kPacket - 1) / kPacket;
-            const size_t per_dev = ((round_packets + G - 1) / G + 63) / 64 * 64;      // whole wavefronts
-            size_t given = 0;
-            for (DeviceBuffers *b : buffers) {
-                b->n_plain = std::min(round_bytes - given, per_dev * kPacket);
-                if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
-                    throw std::runtime_error("Read input file failed");
-                given += b->n_plain;
-            }
-            std::vector<std::thread> workers;
-            for (DeviceBuffers *b : buffers)
-                if (b->n_plain) workers.emplace_back([b] {
-                    try {
-                        b->failure = nullptr;
-                        b->encodeRound();
-                    } catch (...) {
-                        b->failure = std::current_exception();
-                    }
-                });
-            for (auto &w : workers) w.join();
+        int set = 0;
+        auto write_out = [&](int which) {      // output of the finished round that used buffer set `which`
             float slowest = 0;
-            for (DeviceBuffers *b : buffers) {
+            for (size_t g = 0; g < G; ++g) {
+                DeviceBuffers *b = buffers[which * G + g];
                 if (!b->n_plain) continue;
                 if (b->failure) std::rethrow_exception(b->failure);
                 slowest = std::max(slowest, b->kernel_ms);
@@ -211,8 +207,44 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                 info.processedUncompressedSize += b->n_plain;
             }
             kernel_ms_total += slowest;
-            remaining -= round_bytes;
             monitor->updateProgress(&info);
+        };
+        while (remaining > 0) {
+            // contiguous packet ranges, device order = file order (SURVEY.md section 8(e))
+            const size_t round_bytes = std::min(remaining, G * batchPackets * kPacket);
+            const size_t round_packets = (round_bytes + kPacket - 1) / kPacket;
+            const size_t per_dev = ((round_packets + G - 1) / G + 63) / 64 * 64;      // whole wavefronts
+            size_t given = 0;
+            for (size_t g = 0; g < G; ++g) {       // overlaps with the previous round's GPU work
+                DeviceBuffers *b = buffers[set * G + g];
+                b->n_plain = std::min(round_bytes - given, per_dev * kPacket);
+                b->failure = nullptr;
+                if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
+                    throw std::runtime_error("Read input file failed");
+                given += b->n_plain;
+            }
+            std::vector<std::thread> next;
+            const bool had_previous = in_flight.active;
+            if (had_previous) in_flight.join();    // GPUs are free again
+            for (size_t g = 0; g < G; ++g) {
+                DeviceBuffers *b = buffers[set * G + g];
+                if (b->n_plain) next.emplace_back([b] {
+                    try {
+                        b->encodeRound();
+                    } catch (...) {
+                        b->failure = std::current_exception();
+                    }
+                });
+            }
+            in_flight.workers = std::move(next);
+            in_flight.active = true;
+            if (had_previous) write_out(set ^ 1);   // this file write overlaps with the new round's GPU work
+            remaining -= round_bytes;
+            set ^= 1;
+        }
+        if (in_flight.active) {
+            in_flight.join();
+            write_out(set ^ 1);
         }
         FileHeader header;
         header.setCompressedFileSize(info.compressedFileSize);
@@ -222,6 +254,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
             throw std::runtime_error("Write data to file failed");
         closeFiles();
     } catch (...) {
+        in_flight.join();
         closeFiles();
         throw;
     }
@@ -240,6 +273,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
     io_timer.start();
     openFiles();
     double kernel_ms_total = 0;
+    Round in_flight;
     try {
         ensureBuffers();
         FileHeader header;
@@ -247,44 +281,15 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
         info = header.getInfo();
-        const size_t G = buffers.size();
+        const size_t G = devices.size();
         size_t file_pos = FileHeader::HEADER_LENGTH;
         uint8_t hdr[GPUAR_PACKET_HEADER_BYTES];
         bool more = file_pos < fileSize;
-        while (more) {
-            // fill each device with up to batchPackets packets, walking `off += clen`
-            // through the file like src/gpu_compressor.cpp:299-312
-            for (DeviceBuffers *b : buffers) {
-                b->n_packets = 0;
-                b->n_stream = 0;
-                b->h_offsets[0] = 0;
-                while (more && b->n_packets < b->cap) {
-                    if (std::fread(hdr, sizeof hdr, 1, openFile) != 1) throw std::runtime_error("Incorrect file format");
-                    const size_t clen = getPacketSize(hdr);
-                    if (clen < sizeof hdr || clen > kSlot || file_pos + clen > fileSize) throw std::runtime_error("Invalid file length");
-                    std::memcpy(b->h_stream + b->n_stream, hdr, sizeof hdr);
-                    if (clen > sizeof hdr && std::fread(b->h_stream + b->n_stream + sizeof hdr, 1, clen - sizeof hdr, openFile) != clen - sizeof hdr)
-                        throw std::runtime_error("Invalid file length");
-                    b->n_stream += clen;
-                    b->h_offsets[++b->n_packets] = b->n_stream;
-                    file_pos += clen;
-                    more = file_pos < fileSize;
-                }
-            }
-            (void)G;
-            std::vector<std::thread> workers;
-            for (DeviceBuffers *b : buffers)
-                if (b->n_packets) workers.emplace_back([b] {
-                    try {
-                        b->failure = nullptr;
-                        b->decodeRound();
-                    } catch (...) {
-                        b->failure = std::current_exception();
-                    }
-                });
-            for (auto &w : workers) w.join();
+        int set = 0;
+        auto write_out = [&](int which) {
             float slowest = 0;
-            for (DeviceBuffers *b : buffers) {
+            for (size_t g = 0; g < G; ++g) {
+                DeviceBuffers *b = buffers[which * G + g];
                 if (!b->n_packets) continue;
                 if (b->failure) std::rethrow_exception(b->failure);
                 slowest = std::max(slowest, b->kernel_ms);
@@ -298,9 +303,54 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             }
             kernel_ms_total += slowest;
             monitor->updateProgress(&info);
+        };
+        while (more) {
+            // fill each device with up to batchPackets packets, walking `off += clen`
+            // through the file like src/gpu_compressor.cpp:299-312
+            for (size_t g = 0; g < G; ++g) {
+                DeviceBuffers *b = buffers[set * G + g];
+                b->n_packets = 0;
+                b->n_stream = 0;
+                b->h_offsets[0] = 0;
+                b->failure = nullptr;
+                while (more && b->n_packets < b->cap) {
+                    if (std::fread(hdr, sizeof hdr, 1, openFile) != 1) throw std::runtime_error("Incorrect file format");
+                    const size_t clen = getPacketSize(hdr);
+                    if (clen < sizeof hdr || clen > kSlot || file_pos + clen > fileSize) throw std::runtime_error("Invalid file length");
+                    std::memcpy(b->h_stream + b->n_stream, hdr, sizeof hdr);
+                    if (clen > sizeof hdr && std::fread(b->h_stream + b->n_stream + sizeof hdr, 1, clen - sizeof hdr, openFile) != clen - sizeof hdr)
+                        throw std::runtime_error("Invalid file length");
+                    b->n_stream += clen;
+                    b->h_offsets[++b->n_packets] = b->n_stream;
+                    file_pos += clen;
+                    more = file_pos < fileSize;
+                }
+            }
+            std::vector<std::thread> next;
+            const bool had_previous = in_flight.active;
+            if (had_previous) in_flight.join();
+            for (size_t g = 0; g < G; ++g) {
+                DeviceBuffers *b = buffers[set * G + g];
+                if (b->n_packets) next.emplace_back([b] {
+                    try {
+                        b->decodeRound();
+                    } catch (...) {
+                        b->failure = std::current_exception();
+                    }
+                });
+            }
+            in_flight.workers = std::move(next);
+            in_flight.active = true;
+            if (had_previous) write_out(set ^ 1);
+            set ^= 1;
+        }
+        if (in_flight.active) {
+            in_flight.join();
+            write_out(set ^ 1);
         }
         closeFiles();
     } catch (...) {
+        in_flight.join();
         closeFiles();
         throw;
     }

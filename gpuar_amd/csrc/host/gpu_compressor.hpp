@@ -28,14 +28,15 @@ class GPUCompressor : public Compressor {
         return static_cast<unsigned short>(packet[0] | (packet[1] << 8));
     }
 
-    // packets each device takes per round (default 131072 = 1 GiB of input)
-    void setBatchPackets(size_t n) { batchPackets = n; }
+    // packets each device takes per round (default 32768 = 256 MiB of input); rounds are
+    // double-buffered, so file reads, GPU work and file writes of neighbouring rounds overlap
+    void setBatchPackets(size_t n) { batchPackets = n < 64 ? 64 : n; }
 
   private:
     struct DeviceBuffers;
     std::vector<int> devices;
     std::vector<DeviceBuffers *> buffers;
-    size_t batchPackets = 131072;
+    size_t batchPackets = 32768;
 
     void releaseBuffers();
     void ensureBuffers();

@@ -1,6 +1,6 @@
 // main.cpp -- the `gpuar` command line (flags and output text of src/main.cpp:59-205).
 //
-//   gpuar c|d --in=F --out=G [--host] [--device=N] [--gpus=K] [--threads=T] [--nointeractive] [--help]
+//   gpuar c|d --in=F --out=G [--host] [--device=N] [--gpus=K] [--threads=T] [--batch=P] [--nointeractive] [--help]
 //
 // Differences from the reference, all on the error side: `--in F` and `--in=F`
 // are both accepted on purpose (the reference's `--in F` works by accident of
@@ -50,6 +50,7 @@ void usage() {
     std::cout << "--device      specify GPU device, otherwise use device 0" << std::endl;
     std::cout << "--gpus        shard the packets over this many GPUs (devices 0..K-1)" << std::endl;
     std::cout << "--threads     host threads for --host (default 1, 0 = all cores)" << std::endl;
+    std::cout << "--batch       packets per GPU per pipeline round (default 32768 = 256 MiB)" << std::endl;
     std::cout << "--nointeractive no interactive mode" << std::endl;
 }
 
@@ -60,6 +61,7 @@ int main(int argc, char **argv) {
     std::string in, out = "output.gip";
     bool has_in = false;
     int device = -1, gpus = 0, threads = 1;
+    long batch = 0;
     for (int i = 1; i < argc; ++i) {
         const char *v = nullptr;
         auto take = [&](const char **dst) {            // value after '=' or in the next argument
@@ -94,6 +96,9 @@ int main(int argc, char **argv) {
         } else if (flag_name_is(argv[i], "threads", &v)) {
             if (!take(&v)) break;
             threads = std::atoi(v);
+        } else if (flag_name_is(argv[i], "batch", &v)) {
+            if (!take(&v)) break;
+            batch = std::atol(v);
         } else {
             std::cerr << "Unknown argument: " << argv[i] << std::endl;
             return 2;
@@ -115,6 +120,7 @@ int main(int argc, char **argv) {
         } else {
             auto *gpu = new GPUCompressor();
             compressor.reset(gpu);
+            if (batch > 0) gpu->setBatchPackets(static_cast<size_t>(batch));
             if (device >= 0) {
                 std::cout << "Choose GPU device: " << device << "." << std::endl;
                 gpu->chooseDevice(device);
