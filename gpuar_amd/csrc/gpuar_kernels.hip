@@ -278,8 +278,9 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
 constexpr uint32_t kScanThreads = 256;
 constexpr uint32_t kScanItems = 16;                        // packets per thread
 constexpr uint32_t kScanTile = kScanThreads * kScanItems;  // 4096 packets per block
-constexpr uint32_t kScanMaxBlocks = 4096;                  // 16 Mi packets = 128 GiB of input per call
-__device__ uint64_t g_tile_prefix[kScanMaxBlocks];
+// Per-tile sums/prefixes live at the start of the OUTPUT stream buffer until the gather overwrites
+// it (one u64 per 4096 packets, and the stream holds >= 4 bytes per packet): no global scratch,
+// so compactions on different streams or devices never share state.
 
 __device__ __forceinline__ uint32_t slot_clen(const uint8_t *slots, size_t p) {
     return *reinterpret_cast<const uint16_t *>(slots + p * kSlot);
@@ -310,29 +311,29 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T &block_total) {
 }
 
 __global__ void __launch_bounds__(kScanThreads)
-scan_tile_sums_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets) {
+scan_tile_sums_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint64_t *__restrict__ tile_prefix) {
     const size_t first = static_cast<size_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
     uint32_t sum = 0;
     for (uint32_t k = 0; k < kScanItems; ++k)
         if (first + k < n_packets) sum += slot_clen(slots, first + k);
     uint32_t total;
     block_exclusive_scan(sum, total);
-    if (threadIdx.x == 0) g_tile_prefix[blockIdx.x] = total;
+    if (threadIdx.x == 0) tile_prefix[blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(kScanThreads)
-scan_tile_prefix_kernel(uint32_t n_tiles) {   // one block; n_tiles <= 4096
+scan_tile_prefix_kernel(uint32_t n_tiles, uint64_t *__restrict__ tile_prefix) {   // one block
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
         const uint32_t t = base + threadIdx.x;
-        const uint64_t v = t < n_tiles ? g_tile_prefix[t] : 0;
+        const uint64_t v = t < n_tiles ? tile_prefix[t] : 0;
         // a tile sum fits 32 bits (4096 * 8704); sums over tiles need 64
         uint64_t total;
         const uint64_t excl = block_exclusive_scan<uint64_t>(v, total);
         const uint64_t start = carry;
-        if (t < n_tiles) g_tile_prefix[t] = start + excl;
+        if (t < n_tiles) tile_prefix[t] = start + excl;
         __syncthreads();
         if (threadIdx.x == 0) carry = start + total;
         __syncthreads();
@@ -340,7 +341,8 @@ scan_tile_prefix_kernel(uint32_t n_tiles) {   // one block; n_tiles <= 4096
 }
 
 __global__ void __launch_bounds__(kScanThreads)
-scan_offsets_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint64_t *__restrict__ offsets) {
+scan_offsets_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint64_t *__restrict__ offsets,
+                    const uint64_t *__restrict__ tile_prefix) {
     const size_t first = static_cast<size_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
     uint32_t lens[kScanItems];
     uint32_t sum = 0;
@@ -350,7 +352,7 @@ scan_offsets_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint6
         sum += lens[k];
     }
     uint32_t total;
-    uint64_t run = g_tile_prefix[blockIdx.x] + block_exclusive_scan(sum, total);
+    uint64_t run = tile_prefix[blockIdx.x] + block_exclusive_scan(sum, total);
 #pragma unroll
     for (uint32_t k = 0; k < kScanItems; ++k) {
         if (first + k < n_packets) offsets[first + k] = run;
@@ -499,13 +501,15 @@ int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_strea
         return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
     }
     if (!d_slots || !d_stream) return GPUAR_ERR_ARGUMENT;
-    if (!aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_offsets) & 7u)) return GPUAR_ERR_ALIGNMENT;
+    if (!aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_offsets) & 7u) || (reinterpret_cast<uintptr_t>(d_stream) & 7u))
+        return GPUAR_ERR_ALIGNMENT;
+    if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const size_t tiles = (n_packets + gpuar::kScanTile - 1) / gpuar::kScanTile;
-    if (tiles > gpuar::kScanMaxBlocks) return GPUAR_ERR_ARGUMENT;
     const uint32_t np = static_cast<uint32_t>(n_packets);
-    gpuar::scan_tile_sums_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np);
-    gpuar::scan_tile_prefix_kernel<<<1, gpuar::kScanThreads, 0, s>>>(static_cast<uint32_t>(tiles));
-    gpuar::scan_offsets_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, d_offsets);
+    uint64_t *tile_prefix = reinterpret_cast<uint64_t *>(d_stream);   // scratch until the gather overwrites it
+    gpuar::scan_tile_sums_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, tile_prefix);
+    gpuar::scan_tile_prefix_kernel<<<1, gpuar::kScanThreads, 0, s>>>(static_cast<uint32_t>(tiles), tile_prefix);
+    gpuar::scan_offsets_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, d_offsets, tile_prefix);
     gpuar::gather_kernel<<<static_cast<uint32_t>((n_packets + 3) / 4), 256, 0, s>>>(d_slots, d_offsets, np, d_stream);
     return check_launch();
 }

@@ -11,8 +11,8 @@
  * Plain pointers and sizes only.  All `d_*` / `source` / `destination`
  * pointers are DEVICE pointers owned by the caller (hipMalloc, or any
  * allocator that yields HIP device memory, e.g. a torch CUDA tensor).
- * Nothing here allocates device memory except the explicit workspace calls,
- * and nothing throws across the boundary.
+ * Nothing here allocates device memory or keeps state between calls (except
+ * the per-device status word), and nothing throws across the boundary.
  *
  * Packet geometry (reference: src/gpu.h:8-14):
  *   input  is cut into 8192-byte packets, packet p = bytes [p*8192, ...)
@@ -95,7 +95,10 @@ int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, v
  *   d_offsets[p]   = sum of clen of packets < p   (n_packets+1 entries, u64)
  *   d_stream       = packets back to back, exactly the bytes that follow the
  *                    20-byte header in a .gip file.
- * d_stream needs room for the sum of clen (<= n_packets*8704). */
+ * d_stream (8-byte aligned) needs room for the sum of clen (<= n_packets*8704);
+ * its first bytes serve as scan scratch before the packets are gathered into
+ * it, so the call keeps no state outside its arguments and may run
+ * concurrently on different streams and devices. */
 int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_stream,
                       uint64_t *d_offsets, void *stream);
 
