@@ -120,11 +120,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hook: GPUAR_OVERSUBSCRIBE_DEVICES=1 lets several ranks share one physical GPU (rank -> device
+    # rank % count) with gloo carrying the barrier/size exchange, so the N > 1 flow can be exercised on a
+    # one-GPU box.  The driver's real runs use one GPU per rank and RCCL ("nccl").
+    oversubscribe = os.environ.get("GPUAR_OVERSUBSCRIBE_DEVICES") == "1"
+    local_dev = local_rank % torch.cuda.device_count() if oversubscribe else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    ctl_dev = dev                      # where the control tensors of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if oversubscribe:
+            dist.init_process_group("gloo")
+            ctl_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     H.load()
 
     # ---- this rank's shard: contiguous packet range of the global stream ----
@@ -157,7 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -184,7 +194,7 @@ def main():
         oracle_ok = bool(got.size == want.size and (got == want).all())
     del d_stream
 
-    ok_flags = torch.tensor([int(roundtrip_equal and status == 0 and md5_in == md5_out), c_bytes], dtype=torch.int64, device=dev)
+    ok_flags = torch.tensor([int(roundtrip_equal and status == 0 and md5_in == md5_out), c_bytes], dtype=torch.int64, device=ctl_dev)
     if world > 1:
         all_flags = [torch.zeros_like(ok_flags) for _ in range(world)]
         dist.all_gather(all_flags, ok_flags)

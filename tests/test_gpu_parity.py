@@ -251,3 +251,28 @@ def test_many_mixed_packets_against_oracle(H, oracle_port):
     assert np.array_equal(H.decode(d_slots, npk).cpu().numpy(), data)
     assert np.array_equal(H.decode_stream(d_stream, d_off, npk).cpu().numpy(), data)
     assert H.status() == 0
+
+
+def test_bench_two_rank_flow_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 through torch.distributed.run, both ranks on this box's one GPU (gloo control
+    plane, GPUAR_OVERSUBSCRIBE_DEVICES=1): rank r codes bytes [r*B, (r+1)*B) of the stream, the JSON line
+    aggregates both, every rank's round trip must pass.  (Real multi-GPU runs use RCCL, one GPU per rank.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
+    assert abs(d["compression_ratio"] - 1.00804) < 1e-3
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
