@@ -14,7 +14,9 @@
 #include <string>
 
 #include "cpu_compressor.hpp"
+#ifndef GPUAR_HOST_ONLY
 #include "gpu_compressor.hpp"
+#endif
 
 using namespace gip;
 
@@ -118,6 +120,10 @@ int main(int argc, char **argv) {
             compressor.reset(cpu);
             std::cout << "Attention: execute kernel code on host." << std::endl;
         } else {
+#ifdef GPUAR_HOST_ONLY
+            (void)device; (void)gpus; (void)batch;
+            throw std::runtime_error("this build (gpuar-host) has no GPU path: pass --host, or use gpuar");
+#else
             auto *gpu = new GPUCompressor();
             compressor.reset(gpu);
             if (batch > 0) gpu->setBatchPackets(static_cast<size_t>(batch));
@@ -128,6 +134,7 @@ int main(int argc, char **argv) {
                 std::cout << "Shard packets over " << gpus << " GPUs." << std::endl;
                 gpu->useDevices(gpus);
             }
+#endif
         }
         compressor->setOpenFileName(in);
         compressor->setSaveFileName(out);

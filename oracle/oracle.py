@@ -32,7 +32,9 @@ def build(force: bool = False) -> None:
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O3", "-Wall", "-shared", "-fPIC", "-o", so, src])
     ref_so = os.path.join(HERE, "_ref", "libgpuar_ref.so")
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)):
+    driver = os.path.join(HERE, "ref_driver.cpp")
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)
+                                                 or os.path.getmtime(ref_so) < os.path.getmtime(driver)):
         subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 
@@ -141,6 +143,49 @@ class ReferenceOracle(_Codec):
         out = np.zeros(65536 + 64, dtype=np.uint8)
         n = self._lib.ref_decode_packet(_ptr(a), a.size, _ptr(out))
         return out[:n].tobytes()
+
+    # -- caller-owned model state (what the reference's own callers pass) ----
+    def _model_api(self):
+        lib = self._lib
+        if not hasattr(lib, "_model_ready"):
+            u16p = C.POINTER(C.c_uint16)
+            lib.ref_model_init.restype = None
+            lib.ref_model_init.argtypes = [u16p, u16p]
+            lib.ref_encode_packet_model.restype = C.c_size_t
+            lib.ref_encode_packet_model.argtypes = [_u8p, C.c_uint16, _u8p, u16p, u16p]
+            lib.ref_decode_packet_model.restype = C.c_size_t
+            lib.ref_decode_packet_model.argtypes = [_u8p, C.c_size_t, _u8p, u16p, u16p]
+            lib._model_ready = True
+        return lib
+
+    def model_init(self):
+        """(ranges[257] u16 Fenwick array, total) after initializeAdaptiveProbabilityRangeList."""
+        lib = self._model_api()
+        ranges = np.zeros(257, dtype=np.uint16)
+        total = C.c_uint16(0)
+        lib.ref_model_init(ranges.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(total))
+        return ranges, int(total.value)
+
+    def encode_packet_model(self, data, ranges: np.ndarray, total: int):
+        """arCompress from the given model state; returns (packet, ranges', total')."""
+        lib = self._model_api()
+        a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        src = np.zeros(a.size + 32, dtype=np.uint8)
+        src[:a.size] = a
+        out = np.zeros(4 * PACKET_IN, dtype=np.uint8)
+        r = np.array(ranges, dtype=np.uint16)
+        t = C.c_uint16(total)
+        n = lib.ref_encode_packet_model(_ptr(src), a.size, _ptr(out), r.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(t))
+        return out[:n].tobytes(), r, int(t.value)
+
+    def decode_packet_model(self, pkt: bytes, ranges: np.ndarray, total: int):
+        lib = self._model_api()
+        a = np.frombuffer(pkt, dtype=np.uint8).copy()
+        out = np.zeros(65536 + 64, dtype=np.uint8)
+        r = np.array(ranges, dtype=np.uint16)
+        t = C.c_uint16(total)
+        n = lib.ref_decode_packet_model(_ptr(a), a.size, _ptr(out), r.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(t))
+        return out[:n].tobytes(), r, int(t.value)
 
     def decode_stream(self, stream, n_out: int) -> np.ndarray:
         a = np.ascontiguousarray(stream)

@@ -77,4 +77,47 @@ size_t ref_decode_stream(const uint8_t *stream, size_t n_stream, uint8_t *out)
     return produced;
 }
 
+// ---- model-explicit variants: the caller owns the model state, exactly as the
+// reference's own callers do (src/cpu_compressor.cpp:59-60,159-160; src/main.cpp:27-43).
+// `ranges` is the 257-entry Fenwick array of AdaptiveProbabilityRange (src/gpuar.h:42-48).
+void ref_model_init(uint16_t *ranges, uint16_t *total)
+{
+    AdaptiveProbabilityRange model;
+    probability_t t;
+    initializeAdaptiveProbabilityRangeList(&model, t);
+    memcpy(ranges, model.ranges, sizeof model.ranges);
+    *total = t;
+}
+
+size_t ref_encode_packet_model(const uint8_t *in, uint16_t n, uint8_t *out, uint16_t *ranges, uint16_t *total)
+{
+    static __thread unsigned char staged[kIn + 32] __attribute__((aligned(16)));
+    AdaptiveProbabilityRange model;
+    probability_t t = *total;
+    memcpy(model.ranges, ranges, sizeof model.ranges);
+    memset(staged, 0, sizeof staged);
+    memcpy(staged, in, n);
+    size_t len = arCompress(staged, n, out, model, t);
+    memcpy(ranges, model.ranges, sizeof model.ranges);
+    *total = t;
+    return len;
+}
+
+size_t ref_decode_packet_model(const uint8_t *pkt, size_t avail, uint8_t *out, uint16_t *ranges, uint16_t *total)
+{
+    static __thread unsigned char staged[2 * kSlot + 64];
+    AdaptiveProbabilityRange model;
+    probability_t t = *total;
+    size_t clen = (size_t)pkt[0] | ((size_t)pkt[1] << 8);
+    if (clen > avail) clen = avail;
+    if (clen > 2 * kSlot) return 0;
+    memcpy(model.ranges, ranges, sizeof model.ranges);
+    memset(staged, 0, sizeof staged);
+    memcpy(staged, pkt, clen);
+    size_t n = arDecompress(staged, (uint16_t)clen, out, model, t);
+    memcpy(ranges, model.ranges, sizeof model.ranges);
+    *total = t;
+    return n;
+}
+
 }  // extern "C"

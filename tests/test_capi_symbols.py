@@ -17,8 +17,8 @@ def lib():
     return H.load()
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gpuar_hip.h")).read()
+def declared_symbols(header="gpuar_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
     return sorted(set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text)))
@@ -30,6 +30,16 @@ def test_header_symbols_are_exported(lib):
     assert set(names) == set(H.EXPORTS), (names, H.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_host_codec_symbols_are_exported_by_both_libraries(lib):
+    import ctypes
+    from gpuar_amd import host as HC
+    names = declared_symbols("gpuar_host.h")
+    assert set(names) == set(HC.EXPORTS), (names, HC.EXPORTS)
+    small = ctypes.CDLL(HC.LIB_PATH)
+    for n in names:
+        assert hasattr(small, n) and hasattr(lib, n), n
 
 
 def test_host_only_calls(lib):

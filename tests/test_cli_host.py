@@ -78,3 +78,24 @@ def test_gpu_mode_has_no_silent_cpu_fallback(cli, tmp_path):
     src.write_bytes(b"hello")
     r = run(cli, "c", f"--in={src}", f"--out={tmp_path / 'o.gip'}")
     assert r.returncode == 1 and "No HIP device" in r.stderr
+
+
+def test_host_only_binary_needs_no_gpu_runtime(cli, tmp_path):
+    """gpuar-host: the same CLI built without the GPU classes -- links neither
+    libgpuar_hip.so nor libamdhip64 (GPU-runtime-free --host)."""
+    exe = CLI + "-host"
+    assert os.path.exists(exe)
+    deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "amdhip64" not in deps and "gpuar_hip" not in deps
+    src, gip, back = tmp_path / "in.dat", tmp_path / "out.gip", tmp_path / "back.dat"
+    data = synth.text(3, 100000)
+    data.tofile(src)
+    r = subprocess.run([exe, "c", "--host", f"--in={src}", f"--out={gip}"], capture_output=True, text=True,
+                       env={"PATH": os.environ.get("PATH", ""), "LD_LIBRARY_PATH": ""})
+    assert r.returncode == 0, r.stderr
+    blob = gip.read_bytes()
+    assert len(blob) == 67807 and hashlib.md5(blob[20:]).hexdigest() == "02f5848ec18fa461dd34f35359f85456"
+    assert run(exe, "d", "--host", f"--in={gip}", f"--out={back}").returncode == 0
+    assert back.read_bytes() == data.tobytes()
+    r = run(exe, "c", f"--in={src}", f"--out={gip}")          # no --host: refuses, does not fall back
+    assert r.returncode == 1 and "no GPU path" in r.stderr
