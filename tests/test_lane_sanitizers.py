@@ -59,3 +59,56 @@ def test_lane_codec_is_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([sys.executable, "-c", DRIVER % {"tests": HERE, "root": ROOT, "so": so}],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SANITIZED-OK" in r.stdout, r.stderr[-3000:]
+
+
+HOST_DRIVER = r'''
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+from gpuar_amd import synth
+from oracle import oracle as O
+lib = C.CDLL(%(so)r)
+u8p = C.POINTER(C.c_uint8); u16p = C.POINTER(C.c_uint16)
+lib.arCompress.restype = C.c_uint16; lib.arCompress.argtypes = [u8p, C.c_uint16, u8p, u16p, u16p]
+lib.arDecompress.restype = C.c_uint16; lib.arDecompress.argtypes = [u8p, C.c_uint16, u8p, u16p, u16p]
+lib.initializeAdaptiveProbabilityRangeList.argtypes = [u16p, u16p]
+P = O.PortOracle()
+def fresh():
+    r = np.zeros(257, dtype=np.uint16); t = C.c_uint16(0)
+    lib.initializeAdaptiveProbabilityRangeList(r.ctypes.data_as(u16p), C.byref(t)); return r, t
+rng = np.random.default_rng(11)
+for kind in synth.KINDS:
+    for seed, n in [(1, 0), (2, 1), (3, 17), (4, 4097), (5, 8192)]:
+        data = synth.generate(kind, seed, n)
+        want = P.encode_packet(data.tobytes())
+        src = data.copy() if n else np.zeros(1, dtype=np.uint8)          # exactly n readable bytes
+        out = np.zeros(len(want), dtype=np.uint8)                        # exactly clen writable bytes
+        r, t = fresh()
+        got = lib.arCompress(src.ctypes.data_as(u8p), n, out.ctypes.data_as(u8p), r.ctypes.data_as(u16p), C.byref(t))
+        assert got == len(want) and out.tobytes() == want, (kind, seed, n)
+        pkt = np.frombuffer(want, dtype=np.uint8).copy()                 # exactly clen readable bytes
+        back = np.zeros(max(n, 1), dtype=np.uint8)                       # exactly ulen writable bytes
+        r, t = fresh()
+        m = lib.arDecompress(pkt.ctypes.data_as(u8p), pkt.size, back.ctypes.data_as(u8p), r.ctypes.data_as(u16p), C.byref(t))
+        assert m == n and back[:n].tobytes() == data.tobytes()
+        for _ in range(20):                                              # damaged body: must stay inside both buffers
+            bad = pkt.copy()
+            if bad.size > 4:
+                bad[int(rng.integers(4, bad.size))] ^= 1 << int(rng.integers(0, 8))
+            r, t = fresh()
+            lib.arDecompress(bad.ctypes.data_as(u8p), bad.size, back.ctypes.data_as(u8p), r.ctypes.data_as(u16p), C.byref(t))
+print("SANITIZED-OK")
+'''
+
+
+def test_host_codec_is_clean_under_asan_ubsan(tmp_path):
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not available")
+    so = str(tmp_path / "libgpuar_host_asan.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", so,
+                           os.path.join(ROOT, "gpuar_amd", "csrc", "host", "host_codec.cpp")])
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", HOST_DRIVER % {"tests": HERE, "root": ROOT, "so": so}],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SANITIZED-OK" in r.stdout, r.stderr[-3000:]
