@@ -43,7 +43,7 @@ void run(const char *name) {
     uint32_t *d;
     hipMalloc(&d, 1 << 20);
     const int iters = 2000;
-    for (int waves_per_simd = 1; waves_per_simd <= 2; ++waves_per_simd) {
+    for (int waves_per_simd = 1; waves_per_simd <= 4; ++waves_per_simd) {
         const int wg_per_cu = 4 * waves_per_simd;
         const size_t dyn = 160 * 1024 / wg_per_cu - 512;      // LDS footprint pins the residency
         hipEvent_t a, b;
