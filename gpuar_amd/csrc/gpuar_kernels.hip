@@ -6,12 +6,14 @@
 // (/root/reference/src/gpuar_kernel.cu:894-934, 205-238, 321-367, 787-836) is
 // re-derived here for 64-wide wavefronts (per-lane code: lane_codec.h):
 //
-//  * encode_kernel: two wavefronts per 64 packets -- a MODELER (adaptive
-//    models in LDS: per lane a binary left-count tree, node-major/lane-minor
-//    so lane l always hits bank l & 31; software-pipelined walk that yields
-//    cumLo, cumHi and the count update) and a CODER (interval narrowing by a
-//    wave-uniform reciprocal, closed-form renormalisation, bit sink), joined
-//    by an LDS ring;
+//  * encode_kernel: three working wavefronts per 64 packets -- two MODELERS
+//    (adaptive models in LDS: per lane a binary left-count tree, node-major/
+//    lane-minor so lane l always hits bank l & 31; software-pipelined walks
+//    over depths 0-4 and 5-7 that yield cumLo, cumHi and the count update)
+//    and a CODER (interval narrowing by a wave-uniform reciprocal, closed-form
+//    renormalisation, bit sink), joined by an LDS ring; a fourth, idle
+//    wavefront makes the workgroup cover all four SIMDs so that roles can be
+//    dealt out per SIMD;
 //  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
 //    two 16-byte subtree records per symbol instead of walking eight levels;
 //  * compaction (scan + gather) and synthetic-stream generators.
@@ -32,6 +34,7 @@ namespace gpuar {
 
 __constant__ RecipTable g_recip = RecipTable();
 __device__ uint32_t g_status = 0;
+__device__ uint32_t g_cu_ticket[2048];      // one arrival counter per CU (XCC, SE, SH, CU), see encode_kernel
 
 // Lane's column in a tree row: lanes l and l+32 share a dword (low/high half),
 // so the 32 lanes of each LDS lane-group hit 32 distinct banks whatever node
@@ -71,7 +74,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // ran at 108 GB/s; modeler + coder at 290 GB/s with the modeler's serial
 // stream (45 VALU + 13 LDS per symbol) as the bottleneck; cutting that stream
 // in two puts three wavefronts on every SIMD for the same LDS.  32 KiB tree +
-// 8 KiB ring = 40 KiB per workgroup -> exactly 4 workgroups = 12 wavefronts/CU.
+// 8 KiB ring = 40 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
+// (plus the 4 idle ones that only meet the barriers, see encode_kernel).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPhase = 8;
 
@@ -139,12 +143,33 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
     }
 }
 
-__global__ void __launch_bounds__(3 * kLanes)
+__global__ void __launch_bounds__(4 * kLanes)
 encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
     __shared__ EncodeLds lds;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Role by SIMD, not by wavefront index.  The dispatcher puts the four wavefronts of a workgroup on
+    // four different SIMDs (tools/placement_probe.hip); each workgroup draws a ticket from its CU's
+    // arrival counter and leaves SIMD `ticket & 3` idle, the next three SIMDs take top modeler, low
+    // modeler, coder.  Workgroups retire in arrival order (same work each), so the four resident ones
+    // hold four consecutive tickets and every SIMD hosts exactly one wavefront of each role plus one
+    // idle one -- three-wavefront workgroups land 4/3/3/2 on a third of the CUs instead.  Measured on
+    // uniform 8 GiB: 28.0 ms (3 wavefronts) -> 27.2 (idle 4th) -> 26.7 (roles by SIMD).
+    // If the four SIMD ids are ever not distinct, roles fall back to the wavefront index.
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_ID
+    const uint32_t simd = (hw >> 4) & 3u;
+    uint32_t *hello = &lds.ring[0][0][0][0];                 // ring space, not in use yet
+    if (lane == 0) hello[wave] = simd;
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID
+        hello[4] = atomicAdd(&g_cu_ticket[((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu)], 1u);
+    }
+    __syncthreads();
+    const uint32_t seen = (1u << hello[0]) | (1u << hello[1]) | (1u << hello[2]) | (1u << hello[3]);
+    const uint32_t by_simd = (simd - hello[4] - 1u) & 3u;
+    const uint32_t role = __builtin_amdgcn_readfirstlane(seen == 0xFu ? by_simd : wave);   // 3 = idle
+    __syncthreads();
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const size_t start = packet * kPacket;
@@ -158,6 +183,8 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         run_modeler<TopModeler<7>, 0>(lds, in, lane, len, len_min, n_phases);
     } else if (role == 1) {
         run_modeler<LowModeler<7>, 1>(lds, in, lane, len, len_min, n_phases);
+    } else if (role == 3) {
+        for (uint32_t k = 0; k <= n_phases; ++k) lds_barrier();
     } else {
         // ------------------------------- coder -------------------------------
         // slot address = (wave-uniform base of this block's first slot) + lane * 8704
@@ -478,7 +505,7 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
-    gpuar::encode_kernel<<<blocks, 3 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+    gpuar::encode_kernel<<<blocks, 4 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
     return check_launch();
 }
