@@ -29,6 +29,10 @@
 #define GPUAR_MUL24_VV(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
+// low 32 bits of (hi:lo) >> (s & 31)
+#define GPUAR_ALIGNBIT(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
+// both 16-bit halves of v shifted left by the low half of s (s <= 15), each half on its own
+#define GPUAR_PK_SHL16(v, s) ([](uint32_t v_, uint32_t s_) { uint32_t r_; asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r_) : "v"(s_), "v"(v_)); return r_; }((v), (s)))
 // the load that produces q is issued here, before any later store (no wait is implied)
 #define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
@@ -41,6 +45,8 @@
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
 #define GPUAR_BFM(w, off) (((1u << ((w) & 31u)) - 1u) << ((off) & 31u))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
+#define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
+#define GPUAR_PK_SHL16(v, s) (((((v) & 0xFFFFu) << ((s) & 15u)) & 0xFFFFu) | (((((v) >> 16) << ((s) & 15u)) & 0xFFFFu) << 16))
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #endif
@@ -82,35 +88,15 @@ struct RecipTable {
 
 GPUAR_LANE uint32_t div_total(uint32_t n, Recip rc) { return GPUAR_MULHI(n, rc.mul) >> rc.shift; }
 
-// Interval narrowing (applySymbolRange :256-299); 16-bit state in 32-bit registers.
-GPUAR_LANE void narrow(uint32_t &lo, uint32_t &hi, uint32_t cum_lo, uint32_t cum_hi, Recip rc) {
-    const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-    const uint32_t up = div_total(GPUAR_MUL24_VV(cum_hi, range), rc);
-    const uint32_t dn = div_total(GPUAR_MUL24_VV(cum_lo, range), rc);
-    hi = (lo + up - 1u) & 0xFFFFu;
-    lo = (lo + dn) & 0xFFFFu;
-}
-
 // Closed form of the renormalisation loops (writeEncodedBits :321-367,
-// readEncodedBits :787-836).  The loop first shifts out e = clz16(lo ^ hi)
-// agreeing MSBs; after that the MSBs differ (lo: 0, hi: 1).  An underflow
-// shift leaves lo's MSB 0 and hi's MSB 1 again, so no "agree" case can follow
-// an underflow case: the loop is always e agree-shifts, then u underflow
-// shifts, u = length of the run from bit 14 down where lo has 1 and hi has 0.
-struct Renorm {
-    uint32_t e, u;
-};
-GPUAR_LANE Renorm renorm_split(uint32_t &lo, uint32_t &hi) {
-    Renorm r;
-    r.e = GPUAR_CLZ32(lo ^ hi) - 16u;            // 0..16 (16 when lo == hi)
-    const uint32_t lo1 = (lo << r.e) & 0xFFFFu;
-    const uint32_t hi1 = ((hi << r.e) | ((1u << r.e) - 1u)) & 0xFFFFu;
-    const uint32_t run = lo1 & ~hi1;             // underflow candidates, bit 14 downwards
-    r.u = GPUAR_CLZ32(~(run << 17));             // 0..15 leading ones of bits 14..0
-    lo = (lo1 << r.u) & 0x7FFFu;
-    hi = ((hi1 << r.u) | ((1u << r.u) - 1u) | 0x8000u) & 0xFFFFu;
-    return r;
-}
+// readEncodedBits :787-836), used by CoderLane::step and DecoderLane::step_symbol.
+// The loop first shifts out e = clz16(lo ^ hi) agreeing MSBs; after that the
+// MSBs differ (lo: 0, hi: 1).  An underflow shift leaves lo's MSB 0 and hi's
+// MSB 1 again, so no "agree" case can follow an underflow case: the loop is
+// always e agree-shifts, then u underflow shifts, u = length of the run from
+// bit 14 down where lo has 1 and hi has 0.  With hi kept as nh = 0xFFFF - hi,
+// zeros enter both bounds, "lo ^ hi agrees" reads as leading ones of lo ^ nh,
+// and the underflow run is the leading ones of lo & nh below bit 15.
 
 GPUAR_LANE uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
@@ -532,21 +518,35 @@ struct SubtreeModel {
     GPUAR_LANE void flush() { write_back(owed); }
 };
 
-// Decoder state of one packet: SubtreeModel plus a bit reader of two aligned
-// big-endian dwords (w0:w1) hold the stream at the current position, a third
-// is in flight; one funnel shift per symbol exposes the next 32 bits.
+// Decoder state of one packet: SubtreeModel, the interval as the encoder keeps
+// it (lo | (0xFFFF - hi) << 16, so both bounds renormalise with plain left
+// shifts), the code value as its OFFSET above lo, and a bit reader.
+//
+// Why the offset: every renormalisation step of readEncodedBits (:787-836)
+// subtracts the same constant (0, 0x8000 or 0x4000) from lo, hi and code and
+// then doubles them, pulling one stream bit into code.  code - lo therefore
+// just doubles and takes the bit: after n = e + u steps
+//     off' = (off << n) | next n stream bits,
+// one 64-bit shift of off:window, with none of the masks and the conditional
+// complement the absolute code value needs; getUnscaledCode's numerator
+// ((code - lower) + 1) * total - 1 (:703-716) is off * total + (total - 1).
+//
+// Bit reader: two aligned big-endian dwords (w0:w1) hold the stream at the
+// current position, `rem` (0..31) bits of w0 are still unread, a third dword
+// is in flight; alignbit(w0, w1, rem) is the next 32 stream bits.
 template <uint32_t kRowShift>
 struct DecoderLane {
     SubtreeModel<kRowShift> model;
     uint32_t w0, w1;           // two consecutive stream dwords, big-endian order restored
     uint32_t ahead;            // the dword after w1, still as loaded (swapped only when it moves up,
                                // so the wait for its load lands a whole dword of bits later)
-    uint32_t bit;              // bits of w0 already consumed (0..31)
+    uint32_t rem;              // unread bits of w0 (0..31); 0: the window starts at w1
     uint32_t owed_bits;        // bits consumed by the previous symbol, not yet skipped (done in the
                                // shadow of the next symbol's first record read)
     const uint8_t *next;       // address of the dword after `ahead` (4-byte aligned)
     const uint8_t *limit;
-    uint32_t lo, hi, code;
+    uint32_t p;                // lo | (0xFFFF - hi) << 16
+    uint32_t off;              // code - lo
     uint32_t ulen;
     uint32_t outword;
     bool bad;
@@ -562,13 +562,11 @@ struct DecoderLane {
     }
 
     // the next 32 stream bits, left-aligned
-    GPUAR_LANE uint32_t peek() const {
-        return static_cast<uint32_t>(((static_cast<uint64_t>(w0) << 32) | w1) >> (32u - bit));
-    }
+    GPUAR_LANE uint32_t peek() const { return GPUAR_ALIGNBIT(w0, w1, rem); }
     GPUAR_LANE void skip(uint32_t count) {      // count <= 32
-        bit += count;
-        if (bit >= 32u) {
-            bit -= 32u;
+        const bool refill = rem < count;
+        rem = (rem - count) & 31u;
+        if (refill) {
             w0 = w1;
             w1 = bswap32(ahead);
             // consume the OLD prefetched dword before the new load is issued:
@@ -599,37 +597,49 @@ struct DecoderLane {
         w0 = bswap32(fetch());
         w1 = bswap32(fetch());
         ahead = fetch();
-        bit = 8u * misalign;
-        lo = 0;
-        hi = 0xFFFFu;
-        code = peek() >> 16;    // initializeDecoder :582-603
-        skip(16u);
+        // the first 16 bits of the body are the initial code value (initializeDecoder :582-603)
+        const uint32_t used = 8u * misalign + 16u;            // 16, 24, 32 or 40 bits of w0:w1 are behind us
+        const uint64_t both = (static_cast<uint64_t>(w0) << 32) | w1;
+        p = 0;                                                // lo = 0, hi = 0xFFFF
+        off = static_cast<uint32_t>(both >> (64u - used)) & 0xFFFFu;
+        rem = (32u - used) & 31u;                             // used == 32: w0 is spent, the window starts at w1
+        if (used > 32u) {
+            w0 = w1;
+            w1 = bswap32(ahead);
+            ahead = fetch();
+        }
         owed_bits = 0;
     }
 
     // decodes symbol i and returns it; the caller places it (see put_symbol / flush)
     GPUAR_LANE uint32_t step_symbol(uint32_t i, Recip rc) {
         const uint32_t total = 256u + i;
-        const uint32_t range = ((hi - lo) & 0xFFFFu) + 1u;
-        const uint32_t num = GPUAR_MUL24(((code - lo) & 0xFFFFu) + 1u, total) - 1u;
-        // No symbol owns a code value with floor(num / range) >= total (:873-877,
+        const uint32_t lo = p & 0xFFFFu;
+        const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
+        const uint32_t range = above - (p >> 16);             // hi - lo + 1
+        const uint32_t num = GPUAR_MUL24(off, total) + (total - 1u);
+        // No symbol owns a code value with floor(num / range) >= total, i.e. off >= range (:873-877,
         // where the reference stops decoding the packet).  Such a packet is
         // malformed: flag it and keep going -- the walk stays inside the tree and
         // the output inside its 8192 bytes whatever the bits are.
-        bad = bad || num >= GPUAR_MUL24(range, total);
+        bad = bad || off >= range;
         uint32_t cum_lo, cum_hi;
         const uint32_t sym = model.decode_step(num, range, total, cum_lo, cum_hi, [this]() {
             skip(owed_bits);          // the stream window is next needed at the end of this symbol
         });
-        narrow(lo, hi, cum_lo, cum_hi, rc);
-        const Renorm r = renorm_split(lo, hi);
-        // e agree-shifts and u underflow-shifts pull e + u (<= 31) fresh bits in
-        // below the old code; every underflow shift is `code ^= 0x4000` then a
-        // shift (:805-818), which over u >= 1 shifts amounts to complementing
-        // the final MSB once
-        const uint32_t n = r.e + r.u;
-        const uint32_t fresh = (peek() >> 1) >> (31u - n);
-        code = (((code << n) | fresh) ^ (r.u ? 0x8000u : 0u)) & 0xFFFFu;
+        // applySymbolRange :256-299 on (lo, nh), as CoderLane::step does
+        const uint32_t up = div_total(GPUAR_MUL24_VV(cum_hi, range), rc);
+        const uint32_t dn = div_total(GPUAR_MUL24_VV(cum_lo, range), rc);
+        const uint32_t a = lo + dn;                           // new lo
+        const uint32_t b = above - up;                        // 0xFFFF - new hi
+        const uint32_t off_n = off - dn;
+        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
+        const uint32_t e = GPUAR_CLZ32(~((a ^ b) << 16));
+        const uint32_t a1 = (a << e) & 0xFFFFu, b1 = (b << e) & 0xFFFFu;
+        const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
+        p = GPUAR_PK_SHL16(a1 | (b1 << 16), u) & 0x7FFF7FFFu;
+        const uint32_t n = e + u;                             // <= 31 fresh bits
+        off = static_cast<uint32_t>((((static_cast<uint64_t>(off_n) << 32) | peek()) << n) >> 32);
         owed_bits = n;
         return sym;
     }
