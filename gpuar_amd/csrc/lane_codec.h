@@ -33,6 +33,11 @@
 #define GPUAR_ALIGNBIT(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
 // both 16-bit halves of v shifted left by the low half of s (s <= 15), each half on its own
 #define GPUAR_PK_SHL16(v, s) ([](uint32_t v_, uint32_t s_) { uint32_t r_; asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r_) : "v"(s_), "v"(v_)); return r_; }((v), (s)))
+// x + y + (c ? 1 : 0) as ONE add-with-carry fed by the compare's lane mask (hipcc otherwise builds
+// the same value from selects and ors)
+#define GPUAR_ADDC(x, y, c) ([](uint32_t x_, uint32_t y_, bool c_) { uint32_t r_; unsigned long long co_; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r_), "=s"(co_) : "v"(x_), "v"(y_), "s"(__builtin_amdgcn_ballot_w64(c_))); return r_; }((x), (y), (c)))
+// x is wave-uniform: keep it as ONE scalar register instead of re-deriving it from its parts at every use
+#define GPUAR_UNIFORM(x) asm("" : "+s"(x))
 // the load that produces q is issued here, before any later store (no wait is implied)
 #define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
@@ -47,6 +52,8 @@
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
 #define GPUAR_PK_SHL16(v, s) (((((v) & 0xFFFFu) << ((s) & 15u)) & 0xFFFFu) | (((((v) >> 16) << ((s) & 15u)) & 0xFFFFu) << 16))
+#define GPUAR_ADDC(x, y, c) ((x) + (y) + ((c) ? 1u : 0u))
+#define GPUAR_UNIFORM(x) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #endif
@@ -381,8 +388,8 @@ struct CoderLane {
 // as much as a 16-byte one, and the seven separate u16 reads per subtree were
 // what bounded the previous form of this kernel.)  Same left-count tree as
 // the encoder's, same counts, same sums, same symbols.
-//   records  0..3   : subtrees rooted at the depth-2 nodes (index = top 2 bits)
-//   records  4..35  : subtrees rooted at the depth-5 nodes (index = top 5 bits)
+//   records  0..3   : subtrees rooted at the depth-2 nodes (index = complemented top 2 symbol bits)
+//   records  4..35  : subtrees rooted at the depth-5 nodes (index = complemented top 5 symbol bits)
 // kRecShift = log2(bytes between consecutive records of one lane): 10 on the
 // GPU (64 lanes x 16 B, lane-minor: any 16 lanes of a ds_read_b128 group cover
 // all 64 banks whatever records they address), 4 on the host.
@@ -424,44 +431,47 @@ struct SubtreeModel {
 
     // Three decisions inside the record whose 16 bytes are `q`.  State: `below`
     // = count of symbols left of the current node's range, `upper` = count of
-    // symbols left of its right end; the target is compared against below +
-    // left-count directly.  Every decision is kept as "went LEFT" because that
-    // is what the node update adds.  The decoder never forms the quotient
-    // unscaled = floor(num / range) of getUnscaledCode (:703-716): for an integer
-    // s, unscaled < s  <=>  num < s * range, so each decision is one 24-bit
+    // symbols left of its right end, `npath` = the COMPLEMENTED symbol bits
+    // decided so far, MSB first.  Every decision is kept as "went LEFT": that is
+    // what the node update adds, and npath = 2 * npath + left is one
+    // add-with-carry of the same compare; records and the nodes inside them are
+    // simply stored in complemented order so that npath indexes them directly.
+    // The decoder never forms the quotient unscaled = floor(num / range) of
+    // getUnscaledCode (:703-716): for an integer s, unscaled < s  <=>  num <
+    // s * range  <=>  num + 1 <= s * range, so each decision is one 24-bit
     // multiply and a compare -- exact, and no division by the lane-varying
-    // range.  Record layout (chosen so that the two
-    // candidates of a decision sit in the same half of two dwords and one
-    // select picks both grandchildren at once):
-    //     w0 = a | b0 << 16     w1 = - | b1 << 16     w2 = c0 | c1 << 16     w3 = c2 | c3 << 16
-    // Returns the three decisions as complemented symbol bits (0..7, first = MSB).
-    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t num, uint32_t range, uint32_t &below, uint32_t &upper, uint32_t &nbits) {
+    // range.  Record layout (the two candidates of a decision sit in the same
+    // half of two dwords and one select picks both grandchildren at once; L/R =
+    // left/right child):
+    //     w0 = a | bR << 16     w1 = - | bL << 16     w2 = cRR | cRL << 16     w3 = cLR | cLL << 16
+    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t num1, uint32_t range, uint32_t &below, uint32_t &upper, uint32_t &npath) {
         const uint32_t *w = q.w;
         const uint32_t a = w[0] & 0xFFFFu;
         const uint32_t sa = below + a;
-        const bool la = num < GPUAR_MUL24_VV(sa, range);
+        const bool la = num1 <= GPUAR_MUL24_VV(sa, range);
         below = la ? below : sa;
         upper = la ? sa : upper;
-        const uint32_t b = (la ? w[0] : w[1]) >> 16;
-        const uint32_t cc = la ? w[2] : w[3];                 // both grandchildren under the chosen child
+        npath = GPUAR_ADDC(npath, npath, la);
+        const uint32_t b = (la ? w[1] : w[0]) >> 16;
+        const uint32_t cc = la ? w[3] : w[2];                 // both grandchildren under the chosen child
         const uint32_t sb = below + b;
-        const bool lb = num < GPUAR_MUL24_VV(sb, range);
+        const bool lb = num1 <= GPUAR_MUL24_VV(sb, range);
         below = lb ? below : sb;
         upper = lb ? sb : upper;
-        const uint32_t c = lb ? (cc & 0xFFFFu) : (cc >> 16);
-        const uint32_t sc = below + c;
-        const bool lc = num < GPUAR_MUL24_VV(sc, range);
-        below = lc ? below : sc;
-        upper = lc ? sc : upper;
+        npath = GPUAR_ADDC(npath, npath, lb);
         Path p;
         p.rec = rec;
+        p.off_b = la ? 6u : 2u;
+        p.off_c = 8u + 2u * (npath & 3u);                     // grandchild slots 0..3 = RR, RL, LR, LL
+        const uint32_t c = lb ? (cc >> 16) : (cc & 0xFFFFu);
+        const uint32_t sc = below + c;
+        const bool lc = num1 <= GPUAR_MUL24_VV(sc, range);
+        below = lc ? below : sc;
+        upper = lc ? sc : upper;
+        npath = GPUAR_ADDC(npath, npath, lc);
         p.a = a + (la ? 1u : 0u);
         p.b = b + (lb ? 1u : 0u);
         p.c = c + (lc ? 1u : 0u);
-        p.off_b = la ? 2u : 6u;
-        p.off_c = (la ? 8u : 12u) + (lb ? 0u : 2u);
-        // (off_c - 8) / 2 = 2 * !la + !lb : the first two symbol bits, already in place
-        nbits = ((p.off_c - 8u) ^ 6u) | (lc ? 1u : 0u);       // complemented bits la lb lc
         return p;
     }
     GPUAR_LANE void write_back(const Path &p) {
@@ -470,8 +480,8 @@ struct SubtreeModel {
         store16(p.rec + p.off_c, p.c);
     }
 
-    // The symbol s with cum(s) <= floor(num / range) < cum(s+1); cum_lo = cum(s),
-    // cum_hi = cum(s+1).  Memory-safe for any num (a value beyond the model's
+    // The symbol s with cum(s) <= floor((num1 - 1) / range) < cum(s+1); cum_lo = cum(s),
+    // cum_hi = cum(s+1).  Memory-safe for any num1 (a value beyond the model's
     // total simply walks right).
     // Order of LDS traffic (LDS operations of a wavefront complete in order):
     //   read mid record -> write back the PREVIOUS symbol's low record (mid and
@@ -482,36 +492,35 @@ struct SubtreeModel {
     // `in_shadow()` is called right after the first record read has been issued:
     // work that the symbol search does not depend on goes there.
     template <typename Shadow>
-    GPUAR_LANE uint32_t decode_step(uint32_t num, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi,
+    GPUAR_LANE uint32_t decode_step(uint32_t num1, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi,
                                     Shadow &&in_shadow) {
-        const bool l0 = num < GPUAR_MUL24_VV(root, range);
+        const bool l0 = num1 <= GPUAR_MUL24_VV(root, range);
         uint32_t below = l0 ? 0u : root;
         uint32_t upper = l0 ? root : total;
         const uint32_t h = l0 ? half0 : half1;
         const uint32_t s1 = below + h;
-        const bool l1 = num < GPUAR_MUL24_VV(s1, range);
+        const bool l1 = num1 <= GPUAR_MUL24_VV(s1, range);
         below = l1 ? below : s1;
         upper = l1 ? s1 : upper;
-        const uint32_t n2 = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);  // complemented top two bits
-        uint8_t *rec_mid = col + ((n2 ^ 3u) << kRecShift);
+        uint32_t npath = GPUAR_ADDC(l0 ? 2u : 0u, 0u, l1);    // complemented top two symbol bits
+        uint8_t *rec_mid = col + (npath << kRecShift);
         Quad q_mid = load128(rec_mid);                        // ds_read_b128 #1 ...
         GPUAR_PIN_LOAD(q_mid);
         write_back(owed);                                     // ... with the previous symbol's write-back behind it
         in_shadow();
         root += l0 ? 1u : 0u;                                 // register nodes: also in the shadow of read #1
-        half0 += (l0 && l1) ? 1u : 0u;
-        half1 += (!l0 && l1) ? 1u : 0u;
-        uint32_t n_mid, n_low;
-        const Path p_mid = decide3(rec_mid, q_mid, num, range, below, upper, n_mid);
-        const uint32_t n5 = (n2 << 3) | n_mid;                // complemented top five bits
-        uint8_t *rec_low = col + ((4u + (n5 ^ 31u)) << kRecShift);
+        const uint32_t h_new = h + (l1 ? 1u : 0u);            // the depth-1 node on the path
+        half0 = l0 ? h_new : half0;
+        half1 = l0 ? half1 : h_new;
+        const Path p_mid = decide3(rec_mid, q_mid, num1, range, below, upper, npath);
+        uint8_t *rec_low = col + ((4u + npath) << kRecShift); // npath = complemented top five symbol bits
         Quad q_low = load128(rec_low);                        // ds_read_b128 #2 ...
         GPUAR_PIN_LOAD(q_low);
         write_back(p_mid);                                    // ... with the first write-back behind it
-        owed = decide3(rec_low, q_low, num, range, below, upper, n_low);
+        owed = decide3(rec_low, q_low, num1, range, below, upper, npath);
         cum_lo = below;
         cum_hi = upper;
-        return ((n5 << 3) | n_low) ^ 255u;
+        return npath ^ 255u;
     }
 
     // issue the write-back still owed (call once after the last symbol; harmless if repeated)
@@ -613,18 +622,19 @@ struct DecoderLane {
 
     // decodes symbol i and returns it; the caller places it (see put_symbol / flush)
     GPUAR_LANE uint32_t step_symbol(uint32_t i, Recip rc) {
-        const uint32_t total = 256u + i;
+        uint32_t total = 256u + i;                            // i is the same in every lane
+        GPUAR_UNIFORM(total);
         const uint32_t lo = p & 0xFFFFu;
         const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
         const uint32_t range = above - (p >> 16);             // hi - lo + 1
-        const uint32_t num = GPUAR_MUL24(off, total) + (total - 1u);
+        const uint32_t num1 = GPUAR_MUL24(off, total) + total;   // getUnscaledCode's numerator (:703-716), plus one
         // No symbol owns a code value with floor(num / range) >= total, i.e. off >= range (:873-877,
         // where the reference stops decoding the packet).  Such a packet is
         // malformed: flag it and keep going -- the walk stays inside the tree and
         // the output inside its 8192 bytes whatever the bits are.
         bad = bad || off >= range;
         uint32_t cum_lo, cum_hi;
-        const uint32_t sym = model.decode_step(num, range, total, cum_lo, cum_hi, [this]() {
+        const uint32_t sym = model.decode_step(num1, range, total, cum_lo, cum_hi, [this]() {
             skip(owed_bits);          // the stream window is next needed at the end of this symbol
         });
         // applySymbolRange :256-299 on (lo, nh), as CoderLane::step does
