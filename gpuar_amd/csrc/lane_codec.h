@@ -331,7 +331,7 @@ struct CoderLane {
         const uint32_t a1 = (a << e) & 0xFFFFu, b1 = (b << e) & 0xFFFFu;
         // underflow run: from bit 14 down, lo has 1 and hi has 0  <=>  a1 & b1
         const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
-        p = ((a1 << u) & 0x7FFFu) | (((b1 << u) & 0x7FFFu) << 16);
+        p = GPUAR_PK_SHL16(a1 | (b1 << 16), u) & 0x7FFF7FFFu;   // both halves shifted by u (<= 15), each on its own
         // the e agreed bits (same in lo and hi): top, then `pending` copies of
         // !top, then the rest.  Branch-free for the usual pending <= 16.
         // The e agreed bits (same in lo and hi) leave as: their MSB, then `pending`
