@@ -396,11 +396,13 @@ struct CoderLane {
 // ===========================================================================
 template <uint32_t kRecShift>
 struct SubtreeModel {
-    // What three decisions inside one record leave to be written back.
+    // What three decisions inside one record leave to be written back: the whole record with the
+    // three nodes on the path incremented where the walk went left -- ONE 16-byte store.  (Three
+    // u16 stores of just the changed nodes need fewer vector instructions but two more LDS
+    // instructions per record, and an LDS instruction is the dearer of the two here.)
     struct Path {
         uint8_t *rec;
-        uint32_t a, b, c;          // the three nodes on the path, already incremented where the walk went left
-        uint32_t off_b, off_c;     // byte offsets of b and c inside the record
+        uint32_t w0, w1, w2, w3;
     };
 
     uint8_t *col;                       // this lane's 16-byte column
@@ -414,11 +416,9 @@ struct SubtreeModel {
         half0 = half1 = 64u;
         // nothing owed yet: a write-back that rewrites record 35 with its initial values
         owed.rec = col + ((kRecords - 1u) << kRecShift);
-        owed.a = 4u;
-        owed.b = 2u;
-        owed.c = 1u;
-        owed.off_b = 2u;
-        owed.off_c = 8u;
+        owed.w0 = 4u | (2u << 16);
+        owed.w1 = 2u << 16;
+        owed.w2 = owed.w3 = 1u | (1u << 16);
 #pragma unroll 1
         for (uint32_t r = 0; r < kRecords; ++r) {
             const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
@@ -452,33 +452,33 @@ struct SubtreeModel {
         below = la ? below : sa;
         upper = la ? sa : upper;
         npath = GPUAR_ADDC(npath, npath, la);
-        const uint32_t b = (la ? w[1] : w[0]) >> 16;
+        const uint32_t bw = la ? w[1] : w[0];                 // the chosen child sits in its high half
+        const uint32_t b = bw >> 16;
         const uint32_t cc = la ? w[3] : w[2];                 // both grandchildren under the chosen child
         const uint32_t sb = below + b;
         const bool lb = num1 <= GPUAR_MUL24_VV(sb, range);
         below = lb ? below : sb;
         upper = lb ? sb : upper;
         npath = GPUAR_ADDC(npath, npath, lb);
-        Path p;
-        p.rec = rec;
-        p.off_b = la ? 6u : 2u;
-        p.off_c = 8u + 2u * (npath & 3u);                     // grandchild slots 0..3 = RR, RL, LR, LL
         const uint32_t c = lb ? (cc >> 16) : (cc & 0xFFFFu);
         const uint32_t sc = below + c;
         const bool lc = num1 <= GPUAR_MUL24_VV(sc, range);
         below = lc ? below : sc;
         upper = lc ? sc : upper;
         npath = GPUAR_ADDC(npath, npath, lc);
-        p.a = a + (la ? 1u : 0u);
-        p.b = b + (lb ? 1u : 0u);
-        p.c = c + (lc ? 1u : 0u);
+        // the record with +1 on the path nodes where the walk went left: the child's dword and the
+        // grandchildren's dword are bumped in their selected copies and put back by the same selects
+        const uint32_t bw_new = bw + (lb ? 0x10000u : 0u);
+        const uint32_t cc_new = cc + (lc ? (lb ? 0x10000u : 1u) : 0u);
+        Path p;
+        p.rec = rec;
+        p.w0 = GPUAR_ADDC(la ? w[0] : bw_new, 0u, la);        // a sits in the low half of w0
+        p.w1 = la ? bw_new : w[1];
+        p.w2 = la ? w[2] : cc_new;
+        p.w3 = la ? cc_new : w[3];
         return p;
     }
-    GPUAR_LANE void write_back(const Path &p) {
-        store16(p.rec, p.a);
-        store16(p.rec + p.off_b, p.b);
-        store16(p.rec + p.off_c, p.c);
-    }
+    GPUAR_LANE void write_back(const Path &p) { store128(p.rec, p.w0, p.w1, p.w2, p.w3); }
 
     // The symbol s with cum(s) <= floor((num1 - 1) / range) < cum(s+1); cum_lo = cum(s),
     // cum_hi = cum(s+1).  Memory-safe for any num1 (a value beyond the model's
