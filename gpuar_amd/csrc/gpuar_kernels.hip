@@ -84,6 +84,19 @@ struct EncodeLds {
     uint32_t ring[2][kPhase][2][kLanes];       // 8 KiB: [half][symbol][part][lane], parts add up to cumLo | cumHi << 16
 };
 
+// Which group of 64 packets a workgroup serves.  Workgroups are dealt to the eight XCDs round-robin
+// (blockIdx & 7), each XCD with its own L2.  Serving groups in blockIdx order would give one XCD every
+// eighth group, i.e. packets 512 apart -- and 512 slots (8704 B) or 512 packets (8192 B) apart is a
+// multiple of the L2's set period, so everything an XCD has in flight would fall into a small fraction
+// of its sets.  Instead each XCD walks its own contiguous eighth of the groups.  The grid is rounded up
+// to a multiple of 8; a workgroup whose group does not exist returns at once.  (Measured on uniform
+// 8 GiB: encoder L2 fetches 14.3 -> 9.6 GB, L2 write-backs 21.6 -> 12.4 GB, same run time.  The
+// decoders, whose per-lane stores are whole 64-byte sectors, got slightly worse and keep blockIdx order.)
+__device__ __forceinline__ size_t xcd_contiguous_group(uint32_t block, uint32_t grid) {
+    const uint32_t per_xcd = grid >> 3;                       // grid is a multiple of 8
+    return static_cast<size_t>(block & 7u) * per_xcd + (block >> 3);
+}
+
 // LDS only: the global loads/stores of every wave stay in flight across the barrier
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -97,15 +110,67 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) 
 }
 
 // One modeler wavefront: `Model` is TopModeler<7> (part 0) or LowModeler<7> (part 1).
+//
+// Input fetch: 64 bytes per lane (four back-to-back 16-byte loads of the same 128-byte line) once
+// per CHUNK of eight phases, issued a whole chunk ahead of use.  Lanes sit 8192 bytes apart, so the
+// lines all the packets of an XCD are reading at one moment fall into the same few L2 sets and do
+// not survive until the lane comes back for the next piece: every touch of a line is a fetch from
+// memory (rocprofv3 FETCH_SIZE showed 3.3x the input with 16-byte pieces, two modelers each).
+// Fewer, larger touches are the cure that costs no LDS.
 template <typename Model, uint32_t kPart>
 __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, uint32_t lane, uint32_t len,
                                             uint32_t len_min, uint32_t n_phases) {
-    // 16 input bytes per lane every other phase (one 128-byte line is touched 8 times, not 16)
-    uint4 cur = len ? load16_guarded(in, len) : make_uint4(0, 0, 0, 0);
-    uint4 nxt = len > 16u ? load16_guarded(in + 16, len - 16u) : make_uint4(0, 0, 0, 0);
+    constexpr uint32_t kChunkPhases = 8;                       // phases per fetch
+    constexpr uint32_t kChunk = kChunkPhases * kPhase;         // 64 symbols = 64 bytes = 4 x 16-byte loads
+    constexpr uint32_t kPieces = kChunk / 16u;
     Model model;
-    model.open(lds.tree, 2u * lane_column(lane), cur.x & 0xFFu);
-    for (uint32_t k = 0; k <= n_phases; ++k) {
+    uint32_t k = 0;
+    {
+        const uint32_t first = len ? load16_guarded(in, len).x & 0xFFu : 0u;
+        model.open(lds.tree, 2u * lane_column(lane), first);
+    }
+    // ---- whole chunks that every lane of the wavefront owns completely ----
+    const uint32_t full_chunks = len_min / kChunk;
+    if (full_chunks) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(in);
+        uint4 c[kPieces];
+#pragma unroll
+        for (uint32_t t = 0; t < kPieces; ++t) c[t] = src[t];
+        for (uint32_t q = 0; q < full_chunks; ++q) {
+            uint4 n[kPieces];                                 // the chunk after this one (don't-care past the packet)
+#pragma unroll
+            for (uint32_t t = 0; t < kPieces; ++t) {
+                const uint32_t at = (q + 1u) * kChunk + 16u * t;
+                if (at + 16u <= len) n[t] = src[kPieces * (q + 1u) + t];
+                else if (at < len) n[t] = load16_guarded(in + at, len - at);
+                else n[t] = make_uint4(0, 0, 0, 0);
+            }
+            uint32_t w[kChunk / 4u + 1u];
+#pragma unroll
+            for (uint32_t t = 0; t < kPieces; ++t) w[4 * t] = c[t].x, w[4 * t + 1] = c[t].y, w[4 * t + 2] = c[t].z, w[4 * t + 3] = c[t].w;
+            w[kChunk / 4u] = n[0].x;
+#pragma unroll
+            for (uint32_t ph = 0; ph < kChunkPhases; ++ph) {
+                uint32_t *out = &lds.ring[ph & 1u][0][kPart][lane];      // k = kChunkPhases * q + ph, first term even
+#pragma unroll
+                for (uint32_t j = 0; j < kPhase; ++j) {
+                    const uint32_t i = ph * kPhase + j;                  // symbol index inside the chunk
+                    const uint32_t x = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
+                    const uint32_t x_next = (w[(i + 1) >> 2] >> (8u * ((i + 1) & 3u))) & 0xFFu;
+                    out[j * 2u * kLanes] = model.step(x, 256u + q * kChunk + i, x_next);
+                }
+                lds_barrier();
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < kPieces; ++t) c[t] = n[t];
+        }
+        k = kChunkPhases * full_chunks;
+    }
+    // ---- the rest: the phases that hold the file's ragged tail (or a partly dead wavefront) ----
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    if (k * kPhase < len) cur = load16_guarded(in + k * kPhase, len - k * kPhase);
+    if (k * kPhase + 16u < len) nxt = load16_guarded(in + k * kPhase + 16u, len - (k * kPhase + 16u));
+    for (; k <= n_phases; ++k) {
         if (k < n_phases) {
             const uint32_t base = k * kPhase;
             const bool odd = (k & 1u) != 0u;                   // wave-uniform: second half of `cur`
@@ -116,26 +181,17 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
                 if (ahead < len) nxt = load16_guarded(in + ahead, len - ahead);
             }
             uint32_t *out = &lds.ring[k & 1u][0][kPart][lane];
-            if (base + kPhase <= len_min) {
 #pragma unroll
-                for (uint32_t j = 0; j < kPhase; ++j) {
-                    const uint32_t x = (words[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-                    const uint32_t x_next = (words[(j + 1) >> 2] >> (8u * ((j + 1) & 3u))) & 0xFFu;
-                    out[j * 2u * kLanes] = model.step(x, 256u + base + j, x_next);
-                }
-            } else {                       // the phase that holds the file's ragged tail
-#pragma unroll
-                for (uint32_t q = 0; q < 2; ++q) {
-                    uint32_t w = words[q], w_next = words[q + 1];
+            for (uint32_t q = 0; q < 2; ++q) {
+                uint32_t w = words[q], w_next = words[q + 1];
 #pragma unroll 1
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        const uint32_t i = base + 4u * q + b;
-                        const uint32_t x = w & 0xFFu;
-                        w = (w >> 8) | (w_next << 24);        // next symbol now in the low byte
-                        w_next >>= 8;
-                        if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
-                        out += 2u * kLanes;
-                    }
+                for (uint32_t b = 0; b < 4; ++b) {
+                    const uint32_t i = base + 4u * q + b;
+                    const uint32_t x = w & 0xFFu;
+                    w = (w >> 8) | (w_next << 24);            // next symbol now in the low byte
+                    w_next >>= 8;
+                    if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
+                    out += 2u * kLanes;
                 }
             }
         }
@@ -147,6 +203,8 @@ __global__ void __launch_bounds__(4 * kLanes)
 encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
     __shared__ EncodeLds lds;
 
+    const size_t group = xcd_contiguous_group(blockIdx.x, gridDim.x);
+    if (group * kLanes >= n_packets) return;                 // grid padding: the whole workgroup, before any barrier
     const uint32_t lane = threadIdx.x & 63u;
     // Role by SIMD, not by wavefront index.  The dispatcher puts the four wavefronts of a workgroup on
     // four different SIMDs (tools/placement_probe.hip); each workgroup draws a ticket from its CU's
@@ -170,7 +228,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint32_t by_simd = (simd - hello[4] - 1u) & 3u;
     const uint32_t role = __builtin_amdgcn_readfirstlane(seen == 0xFu ? by_simd : wave);   // 3 = idle
     __syncthreads();
-    const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
+    const size_t packet = group * kLanes + lane;
     const bool live = packet < n_packets;
     const size_t start = packet * kPacket;
     const uint32_t len = live ? static_cast<uint32_t>(size - start < kPacket ? size - start : kPacket) : 0u;
@@ -188,7 +246,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     } else {
         // ------------------------------- coder -------------------------------
         // slot address = (wave-uniform base of this block's first slot) + lane * 8704
-        uint8_t *block_slots = dst + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);
+        uint8_t *block_slots = dst + group * (kLanes * kSlot);
         CoderLane coder;
         coder.open(block_slots, lane * kSlot);
         Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
@@ -504,7 +562,8 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void
     if (!aligned16(d_in) || !aligned16(d_slots)) return GPUAR_ERR_ALIGNMENT;
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
-    const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    const uint32_t groups = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    const uint32_t blocks = (groups + 7u) & ~7u;              // see xcd_contiguous_group
     gpuar::encode_kernel<<<blocks, 4 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
     return check_launch();
