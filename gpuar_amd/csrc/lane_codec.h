@@ -36,6 +36,10 @@
 // x + y + (c ? 1 : 0) as ONE add-with-carry fed by the compare's lane mask (hipcc otherwise builds
 // the same value from selects and ors)
 #define GPUAR_ADDC(x, y, c) ([](uint32_t x_, uint32_t y_, bool c_) { uint32_t r_; unsigned long long co_; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r_), "=s"(co_) : "v"(x_), "v"(y_), "s"(__builtin_amdgcn_ballot_w64(c_))); return r_; }((x), (y), (c)))
+// a + low / high half-word of b in one instruction (the compiler splits it into and/shift + add when a
+// select follows); issued ahead of the compare whose result picks one of them
+#define GPUAR_ADD_LO16(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
+#define GPUAR_ADD_HI16(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // x is wave-uniform: keep it as ONE scalar register instead of re-deriving it from its parts at every use
 #define GPUAR_UNIFORM(x) asm("" : "+s"(x))
 // the load that produces q is issued here, before any later store (no wait is implied)
@@ -53,6 +57,8 @@
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
 #define GPUAR_PK_SHL16(v, s) (((((v) & 0xFFFFu) << ((s) & 15u)) & 0xFFFFu) | (((((v) >> 16) << ((s) & 15u)) & 0xFFFFu) << 16))
 #define GPUAR_ADDC(x, y, c) ((x) + (y) + ((c) ? 1u : 0u))
+#define GPUAR_ADD_LO16(a, b) ((a) + ((b) & 0xFFFFu))
+#define GPUAR_ADD_HI16(a, b) ((a) + ((b) >> 16))
 #define GPUAR_UNIFORM(x) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
@@ -457,11 +463,14 @@ struct SubtreeModel {
         const uint32_t cc = la ? w[3] : w[2];                 // both grandchildren under the chosen child
         const uint32_t sb = below + b;
         const bool lb = num1 <= GPUAR_MUL24_VV(sb, range);
+        // both candidates of the third decision, formed while the compare above settles
+        // (left: below stays; right: below becomes sb)
+        const uint32_t sc_left = GPUAR_ADD_HI16(below, cc);
+        const uint32_t sc_right = GPUAR_ADD_LO16(sb, cc);
         below = lb ? below : sb;
         upper = lb ? sb : upper;
         npath = GPUAR_ADDC(npath, npath, lb);
-        const uint32_t c = lb ? (cc >> 16) : (cc & 0xFFFFu);
-        const uint32_t sc = below + c;
+        const uint32_t sc = lb ? sc_left : sc_right;
         const bool lc = num1 <= GPUAR_MUL24_VV(sc, range);
         below = lc ? below : sc;
         upper = lc ? sc : upper;
