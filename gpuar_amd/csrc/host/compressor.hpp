@@ -36,6 +36,14 @@ class Compressor {
     StopWatch io_timer;
     FILE *openFile = nullptr;
     FILE *saveFile = nullptr;
+    bool writeIndex = false;          // append the packet-offset index trailer (packet_index.hpp)
+
+    // where the packets of an open .gip end: the header's size field when it is sane (the reference's
+    // reading, src/cpu_compressor.cpp:47-56), else the end of the file
+    static size_t streamEnd(const CompressionInfo &info, size_t fileSize) {
+        const size_t claimed = info.compressedFileSize;
+        return claimed >= 20 && claimed <= fileSize ? claimed : fileSize;
+    }
 
     void openFiles();                 // throws std::runtime_error naming the file
 
@@ -46,6 +54,7 @@ class Compressor {
     size_t getFileSize(FILE *stream);
     void setOpenFileName(const std::string &fileName) { openFileName = fileName; }
     void setSaveFileName(const std::string &fileName) { saveFileName = fileName; }
+    void setWriteIndex(bool on) { writeIndex = on; }
     virtual CompressionInfo compress(ProgressMonitor *monitor) = 0;
     virtual CompressionInfo decompress(ProgressMonitor *monitor) = 0;
     void closeFiles();

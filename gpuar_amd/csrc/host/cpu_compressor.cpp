@@ -11,6 +11,7 @@
 
 #include "../lane_codec.h"
 #include "file_header.hpp"
+#include "packet_index.hpp"
 
 namespace gip {
 
@@ -90,6 +91,7 @@ CompressionInfo CPUCompressor::compress(ProgressMonitor *monitor) {
     const unsigned nthreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
     std::vector<uint8_t> in(kBatchPackets * gpuar::kPacket + 16), slots(kBatchPackets * gpuar::kSlot);
     std::vector<uint32_t> clen(kBatchPackets);
+    std::vector<uint16_t> all_clens;                   // for the optional index trailer
     try {
         for (;;) {
             io_timer.start();
@@ -109,12 +111,14 @@ CompressionInfo CPUCompressor::compress(ProgressMonitor *monitor) {
                 if (std::fwrite(slots.data() + p * gpuar::kSlot, clen[p], 1, saveFile) != 1)
                     throw std::runtime_error("Write data to file failed");
                 info.compressedFileSize += clen[p];
+                if (writeIndex) all_clens.push_back(static_cast<uint16_t>(clen[p]));
             }
             io_timer.stop();
             info.processedUncompressedSize += got;
             monitor->updateProgress(&info);
         }
         io_timer.start();
+        if (writeIndex) PacketIndex::write(saveFile, all_clens);
         FileHeader header;
         header.setCompressedFileSize(info.compressedFileSize);
         header.setUncompressedFileSize(info.uncompressedFileSize);
@@ -145,20 +149,31 @@ CompressionInfo CPUCompressor::decompress(ProgressMonitor *monitor) {
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
         info = header.getInfo();
-        std::vector<uint8_t> stream(fileSize - FileHeader::HEADER_LENGTH + 16);
-        const size_t n_stream = fileSize - FileHeader::HEADER_LENGTH;
+        const size_t n_stream = streamEnd(info, fileSize) - FileHeader::HEADER_LENGTH;
+        std::vector<uint16_t> index;
+        const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, FileHeader::HEADER_LENGTH + n_stream, fileSize, index);
+        std::vector<uint8_t> stream(n_stream + 16);
         if (n_stream && std::fread(stream.data(), 1, n_stream, openFile) != n_stream)
             throw std::runtime_error("Invalid file length");
         io_timer.stop();
 
-        // the serial header walk of src/cpu_compressor.cpp:47-56: off += clen
         std::vector<size_t> offsets;
-        for (size_t off = 0; off < n_stream;) {
-            if (n_stream - off < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
-            const size_t c = stream[off] | (static_cast<size_t>(stream[off + 1]) << 8);
-            if (c < gpuar::kHdr || c > n_stream - off) throw std::runtime_error("Incorrect file format");
-            offsets.push_back(off);
-            off += c;
+        if (indexed) {                                 // prefix sum of the stored lengths (already checked against n_stream)
+            offsets.reserve(index.size());
+            size_t off = 0;
+            for (uint16_t c : index) {
+                if (c < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
+                offsets.push_back(off);
+                off += c;
+            }
+        } else {                                       // the serial header walk of src/cpu_compressor.cpp:47-56: off += clen
+            for (size_t off = 0; off < n_stream;) {
+                if (n_stream - off < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
+                const size_t c = stream[off] | (static_cast<size_t>(stream[off + 1]) << 8);
+                if (c < gpuar::kHdr || c > n_stream - off) throw std::runtime_error("Incorrect file format");
+                offsets.push_back(off);
+                off += c;
+            }
         }
         const unsigned nthreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
         std::vector<uint8_t> out(kBatchPackets * gpuar::kPacket);

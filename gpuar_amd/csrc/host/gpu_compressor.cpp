@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "file_header.hpp"
+#include "packet_index.hpp"
 #include "gpuar_hip.h"
 
 namespace gip {
@@ -200,6 +201,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         const size_t G = devices.size();
         size_t remaining = info.uncompressedFileSize;
         int set = 0;
+        std::vector<uint16_t> all_clens;       // for the optional index trailer
         auto write_out = [&](int which) {      // output of the finished round that used buffer set `which`
             float slowest = 0;
             for (size_t g = 0; g < G; ++g) {
@@ -209,6 +211,9 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                 slowest = std::max(slowest, b->kernel_ms);
                 if (b->n_stream && std::fwrite(b->h_stream, 1, b->n_stream, saveFile) != b->n_stream)
                     throw std::runtime_error("Write compressed data to output file failed");
+                if (writeIndex)
+                    for (size_t p = 0; p < b->n_packets; ++p)
+                        all_clens.push_back(static_cast<uint16_t>(b->h_offsets[p + 1] - b->h_offsets[p]));
                 info.compressedFileSize += b->n_stream;
                 info.processedUncompressedSize += b->n_plain;
             }
@@ -252,6 +257,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
             in_flight.join();
             write_out(set ^ 1);
         }
+        if (writeIndex) PacketIndex::write(saveFile, all_clens);
         FileHeader header;
         header.setCompressedFileSize(info.compressedFileSize);
         header.setUncompressedFileSize(info.uncompressedFileSize);
@@ -288,9 +294,13 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             throw std::runtime_error("Incorrect file format");
         info = header.getInfo();
         const size_t G = devices.size();
+        const size_t stream_end = streamEnd(info, fileSize);
         size_t file_pos = FileHeader::HEADER_LENGTH;
-        uint8_t hdr[GPUAR_PACKET_HEADER_BYTES];
-        bool more = file_pos < fileSize;
+        // packet lengths from the index trailer when the file has one (packet_index.hpp)
+        std::vector<uint16_t> index;
+        const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, stream_end, fileSize, index);
+        size_t next_packet = 0;
+        bool more = file_pos < stream_end;
         int set = 0;
         auto write_out = [&](int which) {
             float slowest = 0;
@@ -311,26 +321,49 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             monitor->updateProgress(&info);
         };
         while (more) {
-            // fill each device with up to batchPackets packets, walking `off += clen`
-            // through the file like src/gpu_compressor.cpp:299-312
+            // Fill each device with up to cap packets.  One bulk read per device: with an index the
+            // range and its offsets come from the stored lengths (prefix sum); without one the bytes
+            // are read first and `off += clen` is walked in memory (src/gpu_compressor.cpp:299-312
+            // walks it through the file, two reads per packet), then the file is wound back to the
+            // end of the last whole packet.
             for (size_t g = 0; g < G; ++g) {
                 DeviceBuffers *b = buffers[set * G + g];
                 b->n_packets = 0;
                 b->n_stream = 0;
                 b->h_offsets[0] = 0;
                 b->failure = nullptr;
-                while (more && b->n_packets < b->cap) {
-                    if (std::fread(hdr, sizeof hdr, 1, openFile) != 1) throw std::runtime_error("Incorrect file format");
-                    const size_t clen = getPacketSize(hdr);
-                    if (clen < sizeof hdr || clen > kSlot || file_pos + clen > fileSize) throw std::runtime_error("Invalid file length");
-                    std::memcpy(b->h_stream + b->n_stream, hdr, sizeof hdr);
-                    if (clen > sizeof hdr && std::fread(b->h_stream + b->n_stream + sizeof hdr, 1, clen - sizeof hdr, openFile) != clen - sizeof hdr)
+                if (!more) continue;
+                if (indexed) {
+                    while (next_packet < index.size() && b->n_packets < b->cap) {
+                        const size_t clen = index[next_packet++];
+                        if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot) throw std::runtime_error("Invalid file length");
+                        b->n_stream += clen;
+                        b->h_offsets[++b->n_packets] = b->n_stream;
+                    }
+                    if (b->n_stream && std::fread(b->h_stream, 1, b->n_stream, openFile) != b->n_stream)
                         throw std::runtime_error("Invalid file length");
-                    b->n_stream += clen;
-                    b->h_offsets[++b->n_packets] = b->n_stream;
-                    file_pos += clen;
-                    more = file_pos < fileSize;
+                } else {
+                    const size_t want = std::min(stream_end - file_pos, b->cap * kSlot);
+                    if (std::fread(b->h_stream, 1, want, openFile) != want) throw std::runtime_error("Invalid file length");
+                    size_t off = 0;
+                    while (off < want && b->n_packets < b->cap) {
+                        if (want - off < GPUAR_PACKET_HEADER_BYTES) {
+                            if (file_pos + want == stream_end) throw std::runtime_error("Incorrect file format");
+                            break;                     // header cut by the read window: next round
+                        }
+                        const size_t clen = getPacketSize(b->h_stream + off);
+                        if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot || file_pos + off + clen > stream_end)
+                            throw std::runtime_error("Invalid file length");
+                        if (off + clen > want) break;  // packet cut by the read window: next round
+                        off += clen;
+                        b->h_offsets[++b->n_packets] = off;
+                    }
+                    b->n_stream = off;
+                    if (off != want && std::fseek(openFile, static_cast<long>(file_pos + off), SEEK_SET) != 0)
+                        throw std::runtime_error("Seek file failed");
                 }
+                file_pos += b->n_stream;
+                more = file_pos < stream_end;
             }
             std::vector<std::thread> next;
             const bool had_previous = in_flight.active;

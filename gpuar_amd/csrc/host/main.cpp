@@ -53,13 +53,14 @@ void usage() {
     std::cout << "--gpus        shard the packets over this many GPUs (devices 0..K-1)" << std::endl;
     std::cout << "--threads     host threads for --host (default 1, 0 = all cores)" << std::endl;
     std::cout << "--batch       packets per GPU per pipeline round (default 32768 = 256 MiB)" << std::endl;
+    std::cout << "--index       (compress) append the packet-offset index trailer; decompress uses it when present" << std::endl;
     std::cout << "--nointeractive no interactive mode" << std::endl;
 }
 
 }  // namespace
 
 int main(int argc, char **argv) {
-    bool decompress = false, host = false, help = argc <= 1;
+    bool decompress = false, host = false, help = argc <= 1, index = false;
     std::string in, out = "output.gip";
     bool has_in = false;
     int device = -1, gpus = 0, threads = 1;
@@ -81,6 +82,8 @@ int main(int argc, char **argv) {
             help = true;
         } else if (flag_name_is(argv[i], "host", &v)) {
             host = true;
+        } else if (flag_name_is(argv[i], "index", &v)) {
+            index = true;
         } else if (flag_name_is(argv[i], "nointeractive", &v)) {
         } else if (flag_name_is(argv[i], "in", &v)) {
             if (!take(&v)) break;
@@ -136,6 +139,7 @@ int main(int argc, char **argv) {
             }
 #endif
         }
+        compressor->setWriteIndex(index);
         compressor->setOpenFileName(in);
         compressor->setSaveFileName(out);
         CompressionInfo info;

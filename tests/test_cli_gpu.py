@@ -80,3 +80,29 @@ def test_gpu_cli_shards_over_several_devices(tmp_path):
     # without the test override, asking for more GPUs than exist is an error, not a silent clamp
     r = run("c", f"--in={src}", f"--out={g3}", "--gpus=64")
     assert r.returncode == 1 and "visible" in r.stderr
+
+
+def test_gpu_cli_index_trailer_and_bulk_reads(tmp_path):
+    """--index on the GPU path: same bytes as the host writes, trailer a pure suffix; decode with and
+    without the index, in several rounds (read windows that cut packets), on 1 and on 3 (oversubscribed) devices."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, plain, gidx, hidx = tmp_path / "in.dat", tmp_path / "plain.gip", tmp_path / "gpu_idx.gip", tmp_path / "host_idx.gip"
+    data = synth.text(9, 5 * 1024 * 1024 + 777)
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={plain}", "--batch=192").returncode == 0
+    assert run("c", "--index", f"--in={src}", f"--out={gidx}", "--batch=192").returncode == 0
+    assert run("c", "--index", "--host", "--threads=0", f"--in={src}", f"--out={hidx}").returncode == 0
+    a, b = plain.read_bytes(), gidx.read_bytes()
+    assert b == hidx.read_bytes()                                  # GPU and host write the same indexed file
+    assert b[:len(a)] == a and b[len(a):len(a) + 4] == b"GIPX" and int.from_bytes(b[12:20], "little") == len(a)
+    env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
+    for gip, extra in ((gidx, ["--batch=64"]), (plain, ["--batch=64"]), (gidx, ["--gpus=3", "--batch=128"]), (plain, ["--gpus=3", "--batch=128"]), (gidx, [])):
+        back = tmp_path / "back.dat"
+        r = subprocess.run([CLI, "d", f"--in={gip}", f"--out={back}", *extra], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr
+        assert back.read_bytes() == data.tobytes(), (gip, extra)
+    # a truncated stream is an error, not a crash
+    (tmp_path / "cut.gip").write_bytes(a[:len(a) - 100])
+    r = run("d", f"--in={tmp_path / 'cut.gip'}", f"--out={tmp_path / 'cut.out'}")
+    assert r.returncode == 1 and "file" in r.stderr.lower()

@@ -99,3 +99,44 @@ def test_host_only_binary_needs_no_gpu_runtime(cli, tmp_path):
     assert back.read_bytes() == data.tobytes()
     r = run(exe, "c", f"--in={src}", f"--out={gip}")          # no --host: refuses, does not fall back
     assert r.returncode == 1 and "no GPU path" in r.stderr
+
+
+def test_index_trailer_is_a_pure_suffix(cli, tmp_path):
+    """--index appends the packet-offset index behind the stream: bytes up to the header's size field are
+    those written without it, the header still says 20 + packet bytes (what the reference reads), and both
+    files decode -- with one thread and with all, through gpuar and gpuar-host."""
+    src, plain, indexed = tmp_path / "in.dat", tmp_path / "plain.gip", tmp_path / "indexed.gip"
+    data = synth.zipf(7, 5 * 8192 + 123)
+    data.tofile(src)
+    assert run(cli, "c", "--host", f"--in={src}", f"--out={plain}").returncode == 0
+    assert run(cli, "c", "--host", "--index", f"--in={src}", f"--out={indexed}").returncode == 0
+    a, b = plain.read_bytes(), indexed.read_bytes()
+    assert b[:len(a)] == a and int.from_bytes(b[12:20], "little") == len(a)
+    trailer = b[len(a):]
+    assert trailer[:4] == b"GIPX" and trailer[-4:] == b"XPIG"
+    assert int.from_bytes(trailer[4:8], "little") == 1 and int.from_bytes(trailer[8:16], "little") == 6
+    assert int.from_bytes(trailer[-12:-4], "little") == len(trailer) and len(trailer) % 4 == 0
+    clens = [int.from_bytes(trailer[16 + 2 * i:18 + 2 * i], "little") for i in range(6)]
+    assert sum(clens) == len(a) - 20
+    off = 20
+    for c in clens:                                   # the stored lengths are the packets' own headers
+        assert int.from_bytes(a[off:off + 2], "little") == c
+        off += c
+    for exe, threads in ((cli, "1"), (cli, "0"), (cli + "-host", "0")):
+        back = tmp_path / "back.dat"
+        r = run(exe, "d", "--host", "--threads", threads, f"--in={indexed}", f"--out={back}")
+        assert r.returncode == 0, r.stderr
+        assert back.read_bytes() == data.tobytes()
+    # a damaged trailer is ignored (lengths no longer add up): the reader falls back to the header walk
+    broken = bytearray(b)
+    broken[len(a) + 16] ^= 1
+    (tmp_path / "broken.gip").write_bytes(bytes(broken))
+    assert run(cli, "d", "--host", f"--in={tmp_path / 'broken.gip'}", f"--out={tmp_path / 'b.dat'}").returncode == 0
+    assert (tmp_path / "b.dat").read_bytes() == data.tobytes()
+    # empty input: header + an index of zero packets
+    (tmp_path / "empty").write_bytes(b"")
+    assert run(cli, "c", "--host", "--index", f"--in={tmp_path / 'empty'}", f"--out={tmp_path / 'e.gip'}").returncode == 0
+    e = (tmp_path / "e.gip").read_bytes()
+    assert len(e) == 20 + 28 and int.from_bytes(e[12:20], "little") == 20
+    assert run(cli, "d", "--host", f"--in={tmp_path / 'e.gip'}", f"--out={tmp_path / 'e.back'}").returncode == 0
+    assert (tmp_path / "e.back").read_bytes() == b""
