@@ -55,15 +55,17 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // ---------------------------------------------------------------------------
 // Encode: replaces garCompress + arCompress (src/gpuar_kernel.cu:894-914, 487-531)
 //
-// Workgroup = 3 wavefronts serving the same 64 packets (lane l <-> packet
-// 64*block + l in all three):
-//   wave 0, TOP MODELER: depths 0..4 of the 64 adaptive models (0-1 in
-//           registers, 2-4 in LDS), reads the input bytes, emits its part of
+// Workgroup = 4 wavefronts, three of them working on the same 64 packets (lane l
+// <-> packet 64*group + l in all three); which wavefront plays which role is
+// decided per SIMD at run time (see encode_kernel):
+//   TOP MODELER: depths 0..4 of the 64 adaptive models (0-1 in registers, 2-4
+//           in LDS), reads the input bytes, emits its part of
 //           cumLo | cumHi << 16 per symbol;
-//   wave 1, LOW MODELER: depths 5..7 (LDS) and the x == 255 term, same input,
-//           emits the other part;
-//   wave 2, CODER: adds the two parts, owns the interval state and the bit
-//           sink, turns them into the packet bitstream.
+//   LOW MODELER: depths 5..7 (LDS) and the x == 255 term, same input, emits
+//           the other part;
+//   CODER: adds the two parts, owns the interval state and the bit sink, turns
+//           them into the packet bitstream;
+//   the fourth wavefront only meets the barriers.
 // They meet in a two-half LDS ring of kPhase symbols per half: the modelers
 // fill half (k & 1) while the coder drains the other, one s_barrier per phase.
 //
