@@ -132,16 +132,25 @@ void GPUCompressor::releaseBuffers() {
     buffers.clear();
 }
 
-// two buffer sets per device: while the GPUs work on one round, the host reads
-// the next round's input into the other set and writes the previous round's output
-void GPUCompressor::ensureBuffers() {
-    if (buffers.size() == 2 * devices.size() && !buffers.empty() && buffers[0]->cap == batchPackets) return;
+// Two buffer sets per device: while the GPUs work on one round, the host reads the next round's
+// input into the other set and writes the previous round's output.  Sized for the job at hand: a
+// file of `total_packets` needs at most ceil(total / devices) packets per device per round, and a
+// job that fits one round never touches the second set -- pinned allocations are what a short run
+// of the CLI spends most of its time on.
+void GPUCompressor::ensureBuffers(size_t total_packets) {
+    const size_t G = devices.size();
+    const size_t per_dev = ((total_packets + G - 1) / G + 63) / 64 * 64;
+    const size_t cap = std::max<size_t>(64, std::min(batchPackets, per_dev));
+    const bool one_round = total_packets <= G * cap;
+    const bool have = buffers.size() == 2 * G && !buffers.empty() && buffers[0]->cap >= cap && buffers[0]->cap <= batchPackets &&
+                      (one_round || buffers[G]->cap == buffers[0]->cap);
+    if (have) return;
     releaseBuffers();
     for (int set = 0; set < 2; ++set)
         for (int dev : devices) {
             DeviceBuffers *b = new DeviceBuffers();
             buffers.push_back(b);
-            b->allocate(dev, batchPackets);
+            if (set == 0 || !one_round) b->allocate(dev, cap);
         }
 }
 
@@ -194,8 +203,9 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     double kernel_ms_total = 0;
     Round in_flight;
     try {
-        ensureBuffers();
         info.uncompressedFileSize = getFileSize(openFile);
+        ensureBuffers((info.uncompressedFileSize + kPacket - 1) / kPacket);
+        const size_t roundPackets = buffers[0]->cap;       // packets per device per round
         if (std::fseek(saveFile, FileHeader::HEADER_LENGTH, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
         info.compressedFileSize = FileHeader::HEADER_LENGTH;
         const size_t G = devices.size();
@@ -222,12 +232,13 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         };
         while (remaining > 0) {
             // contiguous packet ranges, device order = file order
-            const size_t round_bytes = std::min(remaining, G * batchPackets * kPacket);
+            const size_t round_bytes = std::min(remaining, G * roundPackets * kPacket);
             const size_t round_packets = (round_bytes + kPacket - 1) / kPacket;
             const size_t per_dev = ((round_packets + G - 1) / G + 63) / 64 * 64;      // whole wavefronts
             size_t given = 0;
             for (size_t g = 0; g < G; ++g) {       // overlaps with the previous round's GPU work
                 DeviceBuffers *b = buffers[set * G + g];
+                if (!b->cap) b->allocate(devices[g], roundPackets);       // second set, first needed now
                 b->n_plain = std::min(round_bytes - given, per_dev * kPacket);
                 b->failure = nullptr;
                 if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
@@ -287,12 +298,13 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
     double kernel_ms_total = 0;
     Round in_flight;
     try {
-        ensureBuffers();
         FileHeader header;
         const size_t fileSize = getFileSize(openFile);
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
         info = header.getInfo();
+        // every packet but the last holds 8192 bytes; a packet is at least 4 bytes long, which bounds a lying header
+        ensureBuffers(std::min((info.uncompressedFileSize + kPacket - 1) / kPacket, fileSize / GPUAR_PACKET_HEADER_BYTES + 1));
         const size_t G = devices.size();
         const size_t stream_end = streamEnd(info, fileSize);
         size_t file_pos = FileHeader::HEADER_LENGTH;
@@ -328,6 +340,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             // end of the last whole packet.
             for (size_t g = 0; g < G; ++g) {
                 DeviceBuffers *b = buffers[set * G + g];
+                if (!b->cap) b->allocate(devices[g], buffers[g]->cap);    // second set, first needed now (the header understated the file)
                 b->n_packets = 0;
                 b->n_stream = 0;
                 b->h_offsets[0] = 0;

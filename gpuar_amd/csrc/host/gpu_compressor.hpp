@@ -39,7 +39,7 @@ class GPUCompressor : public Compressor {
     size_t batchPackets = 32768;
 
     void releaseBuffers();
-    void ensureBuffers();
+    void ensureBuffers(size_t total_packets);
 };
 
 }  // namespace gip
