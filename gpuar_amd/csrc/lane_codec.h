@@ -27,6 +27,9 @@
 #define GPUAR_BFM(w, off) ([](uint32_t w_, uint32_t o_) { uint32_t r_; asm("v_bfm_b32 %0, %1, %2" : "=v"(r_) : "v"(w_), "v"(o_)); return r_; }((w), (off)))
 // the same where hipcc cannot see the 24-bit bound by itself (it would emit and + v_mul_lo_u32)
 #define GPUAR_MUL24_VV(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
+// a * b + c with 24-bit factors in ONE instruction (hipcc prefers separate multiplies and three-operand
+// adds to shorten the dependency chain; these kernels are bound by instruction count, not by latency)
+#define GPUAR_MAD24(a, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t r_; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "v"(b_), "v"(c_)); return r_; }((a), (b), (c)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // low 32 bits of (hi:lo) >> (s & 31)
@@ -54,6 +57,7 @@
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
 #define GPUAR_BFM(w, off) (((1u << ((w) & 31u)) - 1u) << ((off) & 31u))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
+#define GPUAR_MAD24(a, b, c) ((a) * (b) + (c))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
 #define GPUAR_PK_SHL16(v, s) (((((v) & 0xFFFFu) << ((s) & 15u)) & 0xFFFFu) | (((((v) >> 16) << ((s) & 15u)) & 0xFFFFu) << 16))
 #define GPUAR_ADDC(x, y, c) ((x) + (y) + ((c) ? 1u : 0u))
@@ -237,11 +241,11 @@ struct PartialModeler {
         if (kTail) acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);  // x == 255: cumHi is the whole total
         if (kHead) {
             const uint32_t pick0 = (z >> 7) & 0x10001u;
-            acc += GPUAR_MUL24(root, pick0);
+            acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
             const bool upper_half = x >= 128u;
             const uint32_t pick1 = (z >> 6) & 0x10001u;
-            acc += GPUAR_MUL24(upper_half ? half1 : half0, pick1);
+            acc = GPUAR_MAD24(upper_half ? half1 : half0, pick1, acc);
             const uint32_t quarter = x >> 6;
             half0 += quarter == 0u ? 1u : 0u;
             half1 += quarter == 2u ? 1u : 0u;
@@ -250,7 +254,7 @@ struct PartialModeler {
         for (int k = 0; k < kDepths; ++k) {
             const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
-            acc += GPUAR_MUL24(l, pick);
+            acc = GPUAR_MAD24(l, pick, acc);
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
             where[k] = tree.node(xn, kFirst + k);
             left[k] = *where[k];
