@@ -58,8 +58,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // Workgroup = 4 wavefronts, three of them working on the same 64 packets (lane l
 // <-> packet 64*group + l in all three); which wavefront plays which role is
 // decided per SIMD at run time (see encode_kernel):
-//   TOP MODELER: depths 0..4 of the 64 adaptive models (0-1 in registers, 2-4
-//           in LDS), reads the input bytes, emits its part of
+//   TOP MODELER: depths 0..4 of the 64 adaptive models (depth 0 in a register,
+//           1-4 in LDS), reads the input bytes, emits its part of
 //           cumLo | cumHi << 16 per symbol;
 //   LOW MODELER: depths 5..7 (LDS) and the x == 255 term, same input, emits
 //           the other part;

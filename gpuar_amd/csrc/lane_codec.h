@@ -197,7 +197,7 @@ struct InorderModel {
 
 // One partial modeler owns depths [kFirst, kFirst + kDepths) of the tree (its
 // rows of the shared table are disjoint from the other's), optionally the
-// register-resident depths 0 and 1 (kHead) and the x == 255 term (kTail), and
+// kHead register-resident depths (0, 1 or 2 of depths 0 and 1) and the x == 255 term (kTail), and
 // returns its part of cumLo | cumHi << 16 (both halves stay below 2^16, so the
 // packed add of the parts cannot carry across).  Software-pipelined: while
 // symbol i is being accounted, this part's nodes of symbol i+1 are already
@@ -205,10 +205,10 @@ struct InorderModel {
 // for symbol i, and LDS operations of a wavefront complete in order, so a node
 // shared by both symbols is read with symbol i's increment applied.  The node
 // addresses travel with the prefetched values.
-template <uint32_t kRowShift, int kFirst, int kDepths, bool kHead, bool kTail>
+template <uint32_t kRowShift, int kFirst, int kDepths, int kHead, bool kTail>
 struct PartialModeler {
     InorderModel<kRowShift> tree;
-    uint32_t root, half0, half1;            // kHead only: depths 0 and 1
+    uint32_t root, half0, half1;            // kHead >= 1: depth 0; kHead == 2: depth 1 as well
     uint32_t left[kDepths];                 // this part's nodes of the NEXT symbol to account
     uint16_t *where[kDepths];
 
@@ -239,10 +239,12 @@ struct PartialModeler {
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
         uint32_t acc = 0;
         if (kTail) acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);  // x == 255: cumHi is the whole total
-        if (kHead) {
+        if (kHead >= 1) {
             const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
+        }
+        if (kHead >= 2) {
             const bool upper_half = x >= 128u;
             const uint32_t pick1 = (z >> 6) & 0x10001u;
             acc = GPUAR_MAD24(upper_half ? half1 : half0, pick1, acc);
@@ -264,9 +266,9 @@ struct PartialModeler {
 };
 
 template <uint32_t kRowShift>
-using TopModeler = PartialModeler<kRowShift, 2, 3, true, false>;    // depths 0..4
+using TopModeler = PartialModeler<kRowShift, 1, 4, 1, false>;       // depths 0..4 (depth 0 in a register)
 template <uint32_t kRowShift>
-using LowModeler = PartialModeler<kRowShift, 5, 3, false, true>;    // depths 5..7 and the x == 255 term
+using LowModeler = PartialModeler<kRowShift, 5, 3, 0, true>;        // depths 5..7 and the x == 255 term
 
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
 // State: lo and nh = 0xFFFF - hi packed as lo | nh << 16, so that both bounds
