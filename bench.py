@@ -16,7 +16,7 @@ compression ratio and the round-trip check are reported next to it.
 Workload (default): uniform(42) stream, 8 GiB per GPU -- the size
 BASELINE.json's north_star quotes its single-GPU encode target on.  The 64 MiB
 stand-in for data/random_64m.dat (configs[1]) is timed too and reported under
-"small_config" (it cannot fill the chip: 8192 packets = 128 wavefronts).
+"small_config" (it cannot fill the chip: 8192 packets = 128 groups of 64).
 """
 import argparse
 import hashlib
@@ -251,7 +251,7 @@ def main():
         s_stream, s_off = H.compact(s_slots, s_npk)
         s_total = int(s_off[-1].item())
         result["small_config"] = {
-            "workload": "uniform(42) 64 MiB (stand-in for data/random_64m.dat), 1 GPU, 8192 packets = 128 wavefronts",
+            "workload": "uniform(42) 64 MiB (stand-in for data/random_64m.dat), 1 GPU, 8192 packets = 128 groups of 64",
             "encode_GBps": m / (min(e) * 1e-3) / 1e9, "decode_GBps": m / (min(d) * 1e-3) / 1e9,
             "gip_bytes": s_total + 20,
             "stream_md5": hashlib.md5(s_stream[:s_total].cpu().numpy().tobytes()).hexdigest(),
