@@ -294,10 +294,11 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 // Decode: replaces garDecompress + arDecompress (:916-934, 848-892)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *pkt, const uint8_t *limit,
+// `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit
+__device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
                                             uint8_t *out, bool live) {
     DecoderLane<10> dec;
-    dec.open(col, pkt, limit, live);
+    dec.open(col, base, pkt_off, limit_off, live);
     const uint32_t len_max = wave_max(dec.ulen);
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
     // Whole blocks of 64 symbols that every lane decodes: no per-lane predicate;
@@ -340,8 +341,9 @@ decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
-    const uint8_t *pkt = slots + (live ? packet : 0) * static_cast<size_t>(kSlot);
-    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), pkt, pkt + kSlot, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+    const uint8_t *group_slots = slots + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);      // wave-uniform
+    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), group_slots, lane * kSlot, (lane + 1u) * kSlot,
+                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
 // Decode from a back-to-back packet stream (the bytes after the 20-byte .gip
@@ -353,9 +355,16 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
-    const uint8_t *pkt = stream + (live ? offsets[packet] : 0);
-    const uint8_t *limit = stream + offsets[n_packets];
-    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), pkt, limit, out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+    // wave-uniform base: the (4-byte aligned) start of this group's first packet
+    const uint64_t first = offsets[static_cast<size_t>(blockIdx.x) * kLanes] & ~3ull;
+    const uint32_t first_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(first >> 32))));
+    const uint32_t first_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(first))));
+    const uint8_t *group_stream = stream + ((static_cast<uint64_t>(first_hi) << 32) | first_lo);
+    const uint64_t left = offsets[n_packets] - first;                       // bytes from the base to the end of the stream
+    const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
+    const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
+    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), group_stream, pkt_off, limit_off,
+                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
 // ---------------------------------------------------------------------------

@@ -44,7 +44,8 @@ size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
 size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
     alignas(16) uint8_t records[gpuar::kDecodeRecords * 16];
     gpuar::DecoderLane<4> dec;
-    dec.open(records, pkt, limit, true);
+    const size_t readable = static_cast<size_t>(limit - pkt);
+    dec.open(records, pkt, 0, readable < 0x7FFFFFFFu ? static_cast<uint32_t>(readable) : 0x7FFFFFFFu, true);
     for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], out);
     dec.finish(out);
     if (dec.bad) throw std::runtime_error("Incorrect file format");

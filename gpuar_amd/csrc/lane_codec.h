@@ -148,6 +148,17 @@ GPUAR_LANE void store16(uint8_t *at, uint32_t v) {
 #endif
 }
 
+// 32-bit load from an address that is 4-byte aligned on the GPU (any alignment on the host)
+GPUAR_LANE uint32_t load32(const uint8_t *at) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const uint32_t *>(at);
+#else
+    uint32_t v;
+    memcpy(&v, at, 4);
+    return v;
+#endif
+}
+
 // 32-bit store to an address that is 4-byte aligned by construction
 GPUAR_LANE void store32(uint8_t *at, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -567,8 +578,9 @@ struct DecoderLane {
     uint32_t rem;              // unread bits of w0 (0..31); 0: the window starts at w1
     uint32_t owed_bits;        // bits consumed by the previous symbol, not yet skipped (done in the
                                // shadow of the next symbol's first record read)
-    const uint8_t *next;       // address of the dword after `ahead` (4-byte aligned)
-    const uint8_t *limit;
+    const uint8_t *base;       // start of the bytes this wavefront reads (the same in every lane: a scalar on the GPU)
+    uint32_t next;             // offset from base of the dword after `ahead` (base + next is 4-byte aligned)
+    uint32_t last;             // offset of the last dword that still holds a readable byte
     uint32_t p;                // lo | (0xFFFF - hi) << 16
     uint32_t off;              // code - lo
     uint32_t ulen;
@@ -576,11 +588,11 @@ struct DecoderLane {
     bool bad;
 
     // An aligned dword that holds at least one readable byte never crosses a
-    // page, so it is loaded whole; bytes past `limit` in it are don't-cares
-    // (a well-formed packet decodes the same whatever follows it).
+    // page, so it is loaded whole; past the last such dword the reader simply
+    // keeps re-reading it (a well-formed packet decodes the same whatever
+    // follows it), which costs one v_min instead of a compare and a branch.
     GPUAR_LANE uint32_t fetch() {
-        uint32_t w = 0;
-        if (next < limit) memcpy(&w, next, 4);
+        const uint32_t w = load32(base + (next < last ? next : last));
         next += 4;
         return w;
     }
@@ -600,24 +612,32 @@ struct DecoderLane {
         }
     }
 
-    GPUAR_LANE void open(uint8_t *col, const uint8_t *pkt, const uint8_t *lim, bool live) {
+    // The packet starts `pkt_off` bytes after `uniform_base`; bytes up to `limit_off` (exclusive, > pkt_off
+    // for a live lane) may be read.  A dead lane (live == false) reads the dword at uniform_base.
+    GPUAR_LANE void open(uint8_t *col, const uint8_t *uniform_base, uint32_t pkt_off, uint32_t limit_off, bool live) {
         model.col = col;
         model.reset();
+        base = uniform_base;
         ulen = 0;
         bad = false;
         outword = 0;
+        uint32_t body = 0;
+        last = 0;
         if (live) {
+            const uint8_t *pkt = base + pkt_off;
             const uint32_t clen = pkt[0] | (static_cast<uint32_t>(pkt[1]) << 8);
             ulen = pkt[2] | (static_cast<uint32_t>(pkt[3]) << 8);
             if (ulen > kPacket || clen < kHdr) {   // the reference would run off its buffers here
                 bad = true;
                 ulen = 0;
             }
+            body = pkt_off + kHdr;
+            // offset of the dword holding byte limit_off - 1, counted from an aligned address
+            const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) & 3u);
+            last = ((limit_off - 1u + skew) & ~3u) - skew;
         }
-        const uint8_t *body = live ? pkt + kHdr : pkt;
-        const uint32_t misalign = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(body) & 3u);
+        const uint32_t misalign = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base + body) & 3u);
         next = body - misalign;
-        limit = live ? lim : pkt;
         w0 = bswap32(fetch());
         w1 = bswap32(fetch());
         ahead = fetch();

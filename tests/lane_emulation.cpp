@@ -54,7 +54,9 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
     for (size_t p = 0; p < np; ++p) {
         DecoderLane<4> dec;
         uint8_t *o = out + p * kPacket;
-        dec.open(reinterpret_cast<uint8_t *>(records.data()), stream + pkt_offsets[p], limit, true);
+        const uint64_t readable = static_cast<uint64_t>(limit - (stream + pkt_offsets[p]));
+        dec.open(reinterpret_cast<uint8_t *>(records.data()), stream + pkt_offsets[p], 0,
+                 readable < 0x7FFFFFFFu ? static_cast<uint32_t>(readable) : 0x7FFFFFFFu, true);
         for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
         dec.finish(o);
         bad += dec.bad ? 1 : 0;
