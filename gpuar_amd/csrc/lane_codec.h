@@ -403,9 +403,8 @@ struct CoderLane {
 // (getSymbolFromProbability :727-763) touches LDS in two round trips of one
 // 16-byte read each instead of walking eight levels.  Depths 0 and 1 of the
 // left-count tree live in registers; depths 2..4 and 5..7 are stored as
-// 3-level subtrees, each one 16-byte RECORD of eight u16
-//     [a | b0 b1 | c0 c1 c2 c3 | pad]
-// so a single ds_read_b128 fetches everything the next three decisions can
+// 3-level subtrees, each one 16-byte RECORD of eight u16 (seven nodes and a
+// pad; exact order at decide3) so a single ds_read_b128 fetches everything the next three decisions can
 // need, and those decisions are then taken in registers.  (Measured with
 // tools/lds_probe.hip: at these occupancies a u16 LDS read costs the CU about
 // as much as a 16-byte one, and the seven separate u16 reads per subtree were
