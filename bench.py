@@ -98,11 +98,30 @@ def cpu_baseline(kind, seed, sample_bytes):
     t2 = time.perf_counter()
     ok = bool((back == data).all())
     enc, dec = data.size / (t1 - t0) / 1e9, data.size / (t2 - t1) / 1e9
-    return {
+    res = {
         "value": data.size / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": codec.kind,
         "sample": f"first {sample_bytes >> 20} MiB of the same {kind}({seed}) stream, encode then decode, 1 thread",
         "encode_GBps": enc, "decode_GBps": dec, "roundtrip_ok": ok, "host_cpus": os.cpu_count(),
     }
+    # Extra row: the same codec with the packets fanned out over host threads --
+    # packets are independent, so this is the fair "all of the host" ceiling.  8 MiB per thread.
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    per = 8 << 20
+    big = synth.generate(kind, seed, threads * per)
+    chunks = [big[t * per:(t + 1) * per] for t in range(threads)]
+    with ThreadPoolExecutor(threads) as pool:            # ctypes calls release the GIL
+        t0 = time.perf_counter()
+        streams = list(pool.map(codec.encode_stream, chunks))
+        t1 = time.perf_counter()
+        backs = list(pool.map(lambda sc: codec.decode_stream(sc[0], sc[1].size), zip(streams, chunks)))
+        t2 = time.perf_counter()
+    res["all_cores"] = {
+        "cores": threads, "sample": f"{threads} x {per >> 20} MiB of the same stream, one contiguous packet range per thread",
+        "value": big.size / (t2 - t0) / 1e9, "encode_GBps": big.size / (t1 - t0) / 1e9, "decode_GBps": big.size / (t2 - t1) / 1e9,
+        "roundtrip_ok": all(bool((b == c).all()) for b, c in zip(backs, chunks)),
+    }
+    return res
 
 
 def main():
