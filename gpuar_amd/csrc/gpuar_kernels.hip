@@ -300,34 +300,41 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     DecoderLane<10> dec;
     dec.open(col, base, pkt_off, limit_off, live);
     const uint32_t len_max = wave_max(dec.ulen);
-    const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
-    // Whole blocks of 64 symbols that every lane decodes: no per-lane predicate;
-    // the 64 output bytes gather in 16 registers and leave as four back-to-back
-    // 16-byte stores, i.e. one whole 64-byte sector of this lane's output line
+    // Whole blocks of 64 symbols: the 64 output bytes gather in 16 registers and leave as four
+    // back-to-back 16-byte stores, i.e. one whole 64-byte sector of this lane's output line
     // at a time (dword-at-a-time stores from 64 lanes at an 8 KiB stride were
     // measured to cost ~10x the output bytes in HBM writes: every partial
-    // sector left L2 before its neighbours arrived).
+    // sector left L2 before its neighbours arrived).  A lane that does not own the whole block -- a
+    // dead lane of the last wavefront, the file's short last packet -- sits the block out with its
+    // state untouched (plain SIMT divergence), so one such lane no longer slows the other 63 down.
     uint32_t i = 0;
-    for (; i + 64u <= len_min; i += 64u) {
-        uint32_t block[16];
+    for (; i + 64u <= len_max; i += 64u) {
+        if (i + 64u <= dec.ulen) {
+            uint32_t block[16];
 #pragma unroll 1
-        for (uint32_t g = 0; g < 16u; ++g) {
-            const uint32_t at = i + 4u * g;                  // wave-uniform
-            Recip rc[4];
+            for (uint32_t g = 0; g < 16u; ++g) {
+                const uint32_t at = i + 4u * g;                  // wave-uniform
+                Recip rc[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[at + j];
-            uint32_t word = 0;
+                for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[at + j];
+                uint32_t word = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) word |= dec.step_symbol(at + j, rc[j]) << (8u * j);
-            block[g] = word;                                 // uniform index: register-indexed move
+                for (uint32_t j = 0; j < 4; ++j) word |= dec.step_symbol(at + j, rc[j]) << (8u * j);
+                block[g] = word;                                 // uniform index: register-indexed move
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+#pragma unroll
+            for (uint32_t v = 0; v < 4; ++v) dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(out + i);
-#pragma unroll
-        for (uint32_t v = 0; v < 4; ++v) dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);
     }
-    for (; i < len_max; ++i) {              // the ragged rest (the file's last packet, or a partial wavefront)
+    // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
+    // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
+    const uint32_t part_from = dec.ulen & ~63u;
+    const uint32_t part_end = wave_max((dec.ulen & 63u) ? dec.ulen : 0u);
+    const uint32_t part_begin = wave_max((dec.ulen & 63u) ? ~part_from : 0u) ^ 0xFFFFFFFFu;   // min over those lanes
+    for (i = part_begin; i < part_end; ++i) {
         const Recip rc = g_recip.r[i];
-        if (i < dec.ulen) dec.step(i, rc, out);
+        if (i >= part_from && i < dec.ulen) dec.step(i, rc, out);
     }
     if (live) {
         dec.finish(out);
