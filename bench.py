@@ -2,10 +2,18 @@
 """bench.py -- encode+decode throughput of the GPUAR packet codec on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
-on rank 0.  For N > 1 the driver launches one process per GPU through
-torch.distributed.run; ranks shard the input stream by contiguous packet
-ranges (no data-path collective -- packets are independent),
-so per-GPU work is fixed and the scaling is "weak".
+on rank 0.  For N > 1 there is one process per GPU: either the caller starts
+them (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+RANK/LOCAL_RANK/WORLD_SIZE in the environment) or -- when WORLD_SIZE is not set
+-- this script starts them itself as child processes, before it has touched
+the GPU, and relays rank 0's line.  Ranks shard the input stream by contiguous
+packet ranges with no data-path collective (packets are independent, SURVEY.md
+8(e)); torch.distributed (RCCL) carries only the barrier, the MAX of the elapsed
+time and the gathering of sizes/flags.
+
+    --scaling weak   (default)  every GPU codes --gib-per-gpu GiB: rank r owns bytes [r*B, (r+1)*B)
+    --scaling strong            --total-gib GiB in all, split into N contiguous packet ranges
+                                (BASELINE.json configs[3]: 8 GiB uniform over 8 GPUs)
 
 A "step" is one pass of the hot path over one batch that is already resident
 in HBM: the encode kernel over the rank's shard, then the decode kernel over
@@ -22,6 +30,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,20 +43,64 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 GIB = 1 << 30
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = ("gpuar_amd/csrc/gpuar_kernels.hip", "gpuar_amd/csrc/lane_codec.h")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "text"])
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--gib-per-gpu", type=float, default=8.0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--gib-per-gpu", type=float, default=8.0, help="weak scaling: GiB each GPU codes")
+    ap.add_argument("--total-gib", type=float, default=8.0, help="strong scaling: GiB split over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def kernel_source_stamp(root=ROOT):
+    """sha256 over the kernel sources: a traffic record is only quoted for the kernels it was taken from."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def self_launch_command(argv, n_gpus, port):
+    """The child command for `python bench.py --gpus N` with no launcher around it: one rank per GPU
+    through torch.distributed.run, rendezvous on 127.0.0.1.  The children are fresh processes; this
+    process has made no GPU call when it starts them (and never execs)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def self_launch(argv, n_gpus):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    child = subprocess.run(self_launch_command(argv, n_gpus, port), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+    for l in child.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return child.returncode if child.returncode or lines else 1
+
+
+def plan_shard(args, world, rank):
+    """(byte offset into the global stream, byte length) this rank codes."""
+    from gpuar_amd import sharding
+    if args.scaling == "strong":
+        total = int(args.total_gib * GIB) // sharding.PACKET * sharding.PACKET
+        return sharding.plan_shards(total, world)[rank]
+    return sharding.weak_shard(int(args.gib_per_gpu * GIB), rank)
 
 
 def timed_kernel_ms(fn, reps):
@@ -61,25 +115,31 @@ def timed_kernel_ms(fn, reps):
     return [a.elapsed_time(b) for a, b in ev]
 
 
-def load_profiled_traffic(args, n_bytes):
-    """HBM bytes per launch from the newest profiles/*_traffic.json (PMC passes of rocprofv3,
-    tools/prof.sh + tools/traffic_from_prof.py), if one exists for this workload size and stream
-    kind; counters cannot be collected from inside this process, so otherwise traffic is null."""
+def load_profiled_traffic(kind, n_bytes, root=ROOT, stamp=None):
+    """HBM bytes per launch (and the issue-side counters) from the newest profiles/*_traffic.json --
+    the PMC passes of rocprofv3 (tools/prof.sh + tools/traffic_from_prof.py); counters cannot be
+    collected from inside this process.  The record is used only if it was taken on this workload
+    size and stream kind AND on the kernel sources that are built now (sha256 stamp); otherwise
+    traffic is null and `traffic_source` says why."""
     import glob
-    out = {}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files or args.kind != "uniform":
-        return out
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
+    if not files:
+        return {"source": "no profiles/*_traffic.json"}
+    name = os.path.basename(files[-1])
     try:
         t = json.load(open(files[-1]))
-    except Exception:
-        return out
-    if abs(t.get("input_gib", 0) * GIB - n_bytes) > 1:
-        return out
+    except Exception as e:                      # noqa: BLE001 -- a damaged record is reported, not fatal
+        return {"source": f"{name}: unreadable ({e})"}
+    if t.get("kind", "uniform") != kind or abs(t.get("input_gib", 0) * GIB - n_bytes) > 1:
+        return {"source": f"{name}: taken on {t.get('kind', 'uniform')} {t.get('input_gib')} GiB, not this workload"}
+    stamp = stamp or kernel_source_stamp(root)
+    if t.get("kernel_source_sha256_16") != stamp:
+        return {"source": f"{name}: STALE -- taken on kernel sources {t.get('kernel_source_sha256_16')}, built sources are "
+                          f"{stamp}; re-run tools/refresh_profiles.sh"}
+    out = {"source": name + ": " + t.get("source", "")}
     for k in ("encode", "decode"):
         if k in t:
-            out[k] = t[k]["hbm_bytes_per_launch"]
-    out["source"] = os.path.basename(files[-1]) + ": " + t.get("source", "")
+            out[k] = t[k]
     return out
 
 
@@ -103,11 +163,12 @@ def cpu_baseline(kind, seed, sample_bytes):
         "sample": f"first {sample_bytes >> 20} MiB of the same {kind}({seed}) stream, encode then decode, 1 thread",
         "encode_GBps": enc, "decode_GBps": dec, "roundtrip_ok": ok, "host_cpus": os.cpu_count(),
     }
-    # Extra row: the same codec with the packets fanned out over host threads --
-    # packets are independent, so this is the fair "all of the host" ceiling.  8 MiB per thread.
+    # Extra row: the same codec with the packets fanned out over EVERY host core
+    # (one thread per logical CPU, one contiguous packet range each) -- packets are independent, so this is
+    # the fair "all of the host" ceiling.
     from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    per = 8 << 20
+    threads = max(1, os.cpu_count() or 1)
+    per = (4 << 20) if threads > 64 else (8 << 20)
     big = synth.generate(kind, seed, threads * per)
     chunks = [big[t * per:(t + 1) * per] for t in range(threads)]
     with ThreadPoolExecutor(threads) as pool:            # ctypes calls release the GIL
@@ -124,8 +185,62 @@ def cpu_baseline(kind, seed, sample_bytes):
     return res
 
 
-def main():
-    args = parse_args()
+def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_rank0, elapsed, enc_ms, dec_ms,
+                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic):
+    """The JSON line, from plain numbers (no GPU objects): the driver's contract fields, the roofline of
+    the dominant kernel and what was verified.  enc_ms / dec_ms are rank 0's average launch durations over
+    its shard of `shard_bytes` bytes; elapsed is the MAX over ranks of the wall time of args.steps steps."""
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes * args.steps / elapsed / 1e9
+    # dominant kernel = the slower of the two; algorithmic bytes per launch = N read/written + C written/read
+    dom = "decode" if dec_ms >= enc_ms else "encode"
+    algo_bytes = shard_bytes + c_bytes_rank0
+
+    def roof(ms, which):
+        a = algo_bytes / (ms * 1e-3) / 1e9
+        t = traffic.get(which) or {}
+        r = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+             "algorithmic_bytes_per_launch": algo_bytes, "traffic": t.get("hbm_bytes_per_launch")}
+        # the roof that actually binds (SURVEY.md section 7 risk 1): vector-issue and wait share of the wavefronts' cycles
+        for k in ("valu_busy", "wait_frac", "valu_insts_per_symbol_step"):
+            if k in t:
+                r[k] = t[k]
+        return r
+
+    if args.scaling == "strong":
+        work = (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPU(s), 8192-byte packets, "
+                f"{npk_rank0} packets on rank 0, shard = contiguous packet range, no collective")
+    else:
+        work = (f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU, 8192-byte packets, "
+                f"{npk_rank0} packets per GPU, shard = contiguous packet range, no collective")
+    return {
+        "metric": "encode+decode GB/s (uncompressed bytes through encode then decode, kernels only, data resident in HBM)",
+        "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "u16 coder state / u32 intermediates", "data": "synthetic",
+        "config": {"workload": work, "parallelism": f"packet-sharded x{world}"},
+        "n_ranks_seen": n_ranks_seen,
+        # rank 0's kernel rate times the number of GPUs (shards are equal to within 64 packets)
+        "encode_GBps": shard_bytes * world / (enc_ms * 1e-3) / 1e9,
+        "decode_GBps": shard_bytes * world / (dec_ms * 1e-3) / 1e9,
+        "encode_ms": enc_ms, "decode_ms": dec_ms,
+        "encode_read_frac_of_hbm_peak": shard_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "compression_ratio": (c_total + 20) / total_bytes,
+        "roundtrip_equal": all_ok, "md5_sample_match": md5_in == md5_out, "md5_sample": md5_in,
+        "oracle_prefix_match": oracle_ok, "device_status": status,
+        "roofline": dict(roof(dec_ms if dom == "decode" else enc_ms, dom), kernel=f"{dom}_kernel"),
+        "roofline_encode": roof(enc_ms, "encode"), "roofline_decode": roof(dec_ms, "decode"),
+        "traffic_source": traffic.get("source"),
+    }
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (children only; nothing here has touched the GPU)
+        raise SystemExit(self_launch(argv, args.gpus))
+
     import torch
     import torch.distributed as dist
     from gpuar_amd import hip as H
@@ -133,10 +248,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # Test hook: GPUAR_OVERSUBSCRIBE_DEVICES=1 lets several ranks share one physical GPU (rank -> device
@@ -157,8 +269,9 @@ def main():
     H.load()
 
     # ---- this rank's shard: contiguous packet range of the global stream ----
-    from gpuar_amd import sharding
-    offset, n = sharding.weak_shard(int(args.gib_per_gpu * GIB), rank)
+    offset, n = plan_shard(args, world, rank)
+    if n == 0:
+        raise SystemExit(f"rank {rank} has no packets: too little data for {world} GPUs")
     npk = H.packet_count(n)
     d_in = H.generate(args.kind, args.seed, n, offset=offset, device=dev)
     d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device=dev)
@@ -207,13 +320,16 @@ def main():
     oracle_ok = None
     if rank == 0:
         from oracle import oracle as O
-        host = d_in[:64 * H.PACKET].cpu().numpy()
+        k = min(64, npk)
+        host = d_in[:min(n, k * H.PACKET)].cpu().numpy()
         want = O.best().encode_stream(host)
-        got = d_stream[:int(d_off[64].item())].cpu().numpy()
+        got = d_stream[:int(d_off[k].item())].cpu().numpy()
         oracle_ok = bool(got.size == want.size and (got == want).all())
     del d_stream
 
-    ok_flags = torch.tensor([int(roundtrip_equal and status == 0 and md5_in == md5_out), c_bytes], dtype=torch.int64, device=ctl_dev)
+    # one row per rank: [round trip ok, compressed bytes, shard bytes, 1]; the last column counts the ranks
+    # the collective really saw
+    ok_flags = torch.tensor([int(roundtrip_equal and status == 0 and md5_in == md5_out), c_bytes, n, 1], dtype=torch.int64, device=ctl_dev)
     if world > 1:
         all_flags = [torch.zeros_like(ok_flags) for _ in range(world)]
         dist.all_gather(all_flags, ok_flags)
@@ -221,42 +337,14 @@ def main():
         all_flags = [ok_flags]
     all_ok = all(int(f[0].item()) == 1 for f in all_flags)
     c_total = sum(int(f[1].item()) for f in all_flags)
+    total_bytes = sum(int(f[2].item()) for f in all_flags)
+    n_ranks_seen = sum(int(f[3].item()) for f in all_flags)
 
     result = None
     if rank == 0:
-        total_bytes = n * world
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_bytes * args.steps / elapsed / 1e9
-        # dominant kernel = the slower of the two; algorithmic bytes per launch = N read/written + C written/read
-        dom = "decode" if dec_avg >= enc_avg else "encode"
-        algo_bytes = n + c_bytes
-
-        traffic = load_profiled_traffic(args, n)
-
-        def roof(ms, which):
-            a = algo_bytes / (ms * 1e-3) / 1e9
-            return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
-                    "algorithmic_bytes_per_launch": algo_bytes, "traffic": traffic.get(which)}
-
-        result = {
-            "metric": "encode+decode GB/s (uncompressed bytes through encode then decode, kernels only, data resident in HBM)",
-            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16 coder state / u32 intermediates", "data": "synthetic",
-            "config": {"workload": f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU, 8192-byte packets, "
-                                   f"{npk} packets per GPU, shard = contiguous packet range, no collective",
-                       "parallelism": f"packet-sharded x{world}"},
-            "encode_GBps": n * world / (enc_avg * 1e-3) / 1e9,
-            "decode_GBps": n * world / (dec_avg * 1e-3) / 1e9,
-            "encode_ms": enc_avg, "decode_ms": dec_avg,
-            "encode_read_frac_of_hbm_peak": n / (enc_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "compression_ratio": (c_total + 20) / total_bytes,
-            "roundtrip_equal": all_ok, "md5_sample_match": md5_in == md5_out, "md5_sample": md5_in,
-            "oracle_prefix_match": oracle_ok, "device_status": status,
-            "roofline": dict(roof(dec_avg if dom == "decode" else enc_avg, dom), kernel=f"{dom}_kernel"),
-            "roofline_encode": roof(enc_avg, "encode"), "roofline_decode": roof(dec_avg, "decode"),
-            "traffic_source": traffic.get("source"),
-        }
+        traffic = load_profiled_traffic(args.kind, n)
+        result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, elapsed, enc_avg, dec_avg, c_bytes, c_total,
+                                 all_ok, md5_in, md5_out, oracle_ok, status, traffic)
 
     # ---- configs[1]: the 64 MiB stand-in for data/random_64m.dat, rank 0 only ----
     if rank == 0 and not args.no_small_config:
@@ -282,7 +370,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.kind, args.seed, args.cpu_sample_mib << 20)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

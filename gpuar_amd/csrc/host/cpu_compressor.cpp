@@ -6,6 +6,8 @@
 #include "cpu_compressor.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -52,6 +54,8 @@ size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
     return dec.ulen;
 }
 
+// f(p) for p in [0, n) on `threads` host threads.  The first exception wins and stops the others
+// at their next packet.
 template <typename F>
 void for_each_packet(size_t n, unsigned threads, F &&f) {
     if (threads <= 1 || n < 2) {
@@ -60,12 +64,16 @@ void for_each_packet(size_t n, unsigned threads, F &&f) {
     }
     std::vector<std::thread> pool;
     std::exception_ptr failure;
+    std::mutex failure_lock;
+    std::atomic<bool> stop{false};
     for (unsigned t = 0; t < threads; ++t)
         pool.emplace_back([&, t] {
             try {
-                for (size_t p = t; p < n; p += threads) f(p);
+                for (size_t p = t; p < n && !stop.load(std::memory_order_relaxed); p += threads) f(p);
             } catch (...) {
-                failure = std::current_exception();
+                std::lock_guard<std::mutex> hold(failure_lock);
+                if (!failure) failure = std::current_exception();
+                stop.store(true, std::memory_order_relaxed);
             }
         });
     for (auto &th : pool) th.join();
@@ -149,41 +157,59 @@ CompressionInfo CPUCompressor::decompress(ProgressMonitor *monitor) {
     try {
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
-        info = header.getInfo();
-        const size_t n_stream = streamEnd(info, fileSize) - FileHeader::HEADER_LENGTH;
+        info = header.getInfo(fileSize);
+        const size_t stream_end = streamEnd(info, fileSize);
         std::vector<uint16_t> index;
-        const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, FileHeader::HEADER_LENGTH + n_stream, fileSize, index);
-        std::vector<uint8_t> stream(n_stream + 16);
-        if (n_stream && std::fread(stream.data(), 1, n_stream, openFile) != n_stream)
-            throw std::runtime_error("Invalid file length");
+        const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, stream_end, fileSize, index);
         io_timer.stop();
 
-        std::vector<size_t> offsets;
-        if (indexed) {                                 // prefix sum of the stored lengths (already checked against n_stream)
-            offsets.reserve(index.size());
-            size_t off = 0;
-            for (uint16_t c : index) {
-                if (c < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
-                offsets.push_back(off);
-                off += c;
-            }
-        } else {                                       // the serial header walk of src/cpu_compressor.cpp:47-56: off += clen
-            for (size_t off = 0; off < n_stream;) {
-                if (n_stream - off < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
-                const size_t c = stream[off] | (static_cast<size_t>(stream[off + 1]) << 8);
-                if (c < gpuar::kHdr || c > n_stream - off) throw std::runtime_error("Incorrect file format");
-                offsets.push_back(off);
-                off += c;
-            }
-        }
+        // The stream is taken in windows of at most kBatchPackets packets, as GPUCompressor does:
+        // memory stays bounded whatever the file size (the 64-bit header exists for 8-64 GiB inputs).
+        // With an index the window's extent comes from the stored lengths; without one the bytes are
+        // read first and `off += clen` is walked in memory (src/cpu_compressor.cpp:47-56 walks it
+        // through the file), then the file is wound back to the end of the last whole packet.
         const unsigned nthreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
-        std::vector<uint8_t> out(kBatchPackets * gpuar::kPacket);
+        std::vector<uint8_t> window(kBatchPackets * gpuar::kSlot + 65536 + 16), out(kBatchPackets * gpuar::kPacket);
+        std::vector<size_t> offsets(kBatchPackets + 1);
         std::vector<uint32_t> ulen(kBatchPackets);
-        for (size_t first = 0; first < offsets.size(); first += kBatchPackets) {
-            const size_t np = std::min(kBatchPackets, offsets.size() - first);
+        size_t file_pos = FileHeader::HEADER_LENGTH, next_packet = 0;
+        while (file_pos < stream_end) {
+            size_t np = 0, bytes = 0;
+            io_timer.start();
+            if (indexed) {
+                offsets[0] = 0;
+                while (next_packet < index.size() && np < kBatchPackets && bytes + index[next_packet] + 16 <= window.size()) {
+                    const size_t c = index[next_packet++];
+                    if (c < gpuar::kHdr) throw std::runtime_error("Incorrect file format");
+                    bytes += c;
+                    offsets[++np] = bytes;
+                }
+                if (!np) throw std::runtime_error("Incorrect file format");
+                if (std::fread(window.data(), 1, bytes, openFile) != bytes) throw std::runtime_error("Invalid file length");
+            } else {
+                const size_t want = std::min(stream_end - file_pos, kBatchPackets * static_cast<size_t>(gpuar::kSlot) + 65536);
+                if (std::fread(window.data(), 1, want, openFile) != want) throw std::runtime_error("Invalid file length");
+                offsets[0] = 0;
+                while (bytes < want && np < kBatchPackets) {
+                    if (want - bytes < gpuar::kHdr) {
+                        if (file_pos + want == stream_end) throw std::runtime_error("Incorrect file format");
+                        break;                             // header cut by the window: next round
+                    }
+                    const size_t c = window[bytes] | (static_cast<size_t>(window[bytes + 1]) << 8);
+                    if (c < gpuar::kHdr || file_pos + bytes + c > stream_end) throw std::runtime_error("Incorrect file format");
+                    if (bytes + c > want) break;           // packet cut by the window: next round
+                    bytes += c;
+                    offsets[++np] = bytes;
+                }
+                if (!np) throw std::runtime_error("Incorrect file format");
+                if (bytes != want && std::fseek(openFile, static_cast<long>(file_pos + bytes), SEEK_SET) != 0)
+                    throw std::runtime_error("Seek file failed");
+            }
+            io_timer.stop();
+            file_pos += bytes;
             process_timer.start();
             for_each_packet(np, nthreads, [&](size_t p) {
-                ulen[p] = static_cast<uint32_t>(decode_one(stream.data() + offsets[first + p], stream.data() + n_stream,
+                ulen[p] = static_cast<uint32_t>(decode_one(window.data() + offsets[p], window.data() + bytes,
                                                            out.data() + p * gpuar::kPacket));
             });
             process_timer.stop();
@@ -196,6 +222,7 @@ CompressionInfo CPUCompressor::decompress(ProgressMonitor *monitor) {
             io_timer.stop();
             monitor->updateProgress(&info);
         }
+        info.uncompressedFileSize = info.processedUncompressedSize;     // what the packets held
         io_timer.start();
         closeFiles();
         io_timer.stop();

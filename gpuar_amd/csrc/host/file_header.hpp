@@ -37,10 +37,21 @@ class FileHeader {
     void *getData() { return data; }
     void setData(const void *src) { std::memcpy(data, src, HEADER_LENGTH); }
 
-    CompressionInfo getInfo() const {
+    // `fileSize` = bytes in the .gip file being read (0: unknown).  The reference writes only the
+    // low 4 bytes of each size and leaves the 4 above them uninitialised, so a 64-bit value is
+    // believed only when the file could hold it: the packet stream ends inside the file, and the
+    // stream is long enough for that many bytes (a packet of <= 8192 bytes takes >= 4).  Otherwise
+    // the low 32 bits are what the writer meant.
+    CompressionInfo getInfo(uint64_t fileSize = 0) const {
         CompressionInfo info;
-        info.uncompressedFileSize = static_cast<size_t>(get64(UNCOMPRESSED_FILE_SIZE_POSITION));
-        info.compressedFileSize = static_cast<size_t>(get64(COMPRESSED_FILE_SIZE_POSITION));
+        uint64_t unc = get64(UNCOMPRESSED_FILE_SIZE_POSITION), comp = get64(COMPRESSED_FILE_SIZE_POSITION);
+        if (fileSize) {
+            if (comp > fileSize) comp &= 0xFFFFFFFFull;
+            const uint64_t stream = (comp >= HEADER_LENGTH && comp <= fileSize ? comp : fileSize) - HEADER_LENGTH;
+            if (unc > (stream / 4 + 1) * 8192) unc &= 0xFFFFFFFFull;
+        }
+        info.uncompressedFileSize = static_cast<size_t>(unc);
+        info.compressedFileSize = static_cast<size_t>(comp);
         return info;
     }
     void setUncompressedFileSize(size_t size) { put64(UNCOMPRESSED_FILE_SIZE_POSITION, size); }

@@ -239,7 +239,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
             for (size_t g = 0; g < G; ++g) {       // overlaps with the previous round's GPU work
                 DeviceBuffers *b = buffers[set * G + g];
                 if (!b->cap) b->allocate(devices[g], roundPackets);       // second set, first needed now
-                b->n_plain = std::min(round_bytes - given, per_dev * kPacket);
+                b->n_plain = std::min(round_bytes - given, std::min(per_dev, b->cap) * kPacket);
                 b->failure = nullptr;
                 if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
                     throw std::runtime_error("Read input file failed");
@@ -302,7 +302,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         const size_t fileSize = getFileSize(openFile);
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
-        info = header.getInfo();
+        info = header.getInfo(fileSize);
         // every packet but the last holds 8192 bytes; a packet is at least 4 bytes long, which bounds a lying header
         ensureBuffers(std::min((info.uncompressedFileSize + kPacket - 1) / kPacket, fileSize / GPUAR_PACKET_HEADER_BYTES + 1));
         const size_t G = devices.size();
@@ -321,13 +321,25 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                 if (!b->n_packets) continue;
                 if (b->failure) std::rethrow_exception(b->failure);
                 slowest = std::max(slowest, b->kernel_ms);
-                // every packet but the file's last one holds 8192 bytes (src/gpu_compressor.cpp:326-331)
-                size_t n = b->n_packets * kPacket;
-                const size_t left = info.uncompressedFileSize - info.processedUncompressedSize;
-                if (n > left) n = left;
-                if (n && std::fwrite(b->h_plain, 1, n, saveFile) != n)
-                    throw std::runtime_error("Write uncompressed data to output file failed");
-                info.processedUncompressedSize += n;
+                // Every packet says how many bytes it holds (u16 at +2); all but the file's last one hold
+                // 8192 (src/gpu_compressor.cpp:326-331).  The lengths written come from the packets, not
+                // from the header's size field: a file written by the reference carries garbage in the
+                // upper half of that field (src/file_header.hpp:31-36), and --host decodes by ulen too.
+                size_t run_begin = 0, run_bytes = 0;       // contiguous bytes of h_plain not yet written
+                auto flush = [&] {
+                    if (run_bytes && std::fwrite(b->h_plain + run_begin, 1, run_bytes, saveFile) != run_bytes)
+                        throw std::runtime_error("Write uncompressed data to output file failed");
+                    info.processedUncompressedSize += run_bytes;
+                    run_bytes = 0;
+                };
+                for (size_t p = 0; p < b->n_packets; ++p) {
+                    const uint8_t *pkt = b->h_stream + b->h_offsets[p];
+                    const size_t ulen = std::min<size_t>(kPacket, pkt[2] | (static_cast<size_t>(pkt[3]) << 8));
+                    if (run_bytes == 0) run_begin = p * kPacket;
+                    run_bytes += ulen;
+                    if (ulen != kPacket) flush();          // a short packet ends the contiguous run
+                }
+                flush();
             }
             kernel_ms_total += slowest;
             monitor->updateProgress(&info);
@@ -400,6 +412,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             in_flight.join();
             write_out(set ^ 1);
         }
+        info.uncompressedFileSize = info.processedUncompressedSize;     // what the packets held
         closeFiles();
     } catch (...) {
         in_flight.join();

@@ -28,9 +28,10 @@ class GPUCompressor : public Compressor {
         return static_cast<unsigned short>(packet[0] | (packet[1] << 8));
     }
 
-    // packets each device takes per round (default 32768 = 256 MiB of input); rounds are
-    // double-buffered, so file reads, GPU work and file writes of neighbouring rounds overlap
-    void setBatchPackets(size_t n) { batchPackets = n < 64 ? 64 : n; }
+    // packets each device takes per round (default 32768 = 256 MiB of input), kept a multiple of 64
+    // (whole wavefronts: compress() deals every device a multiple of 64 packets, which must fit its
+    // buffers); rounds are double-buffered, so file reads, GPU work and file writes of neighbouring rounds overlap
+    void setBatchPackets(size_t n) { batchPackets = n < 64 ? 64 : n / 64 * 64; }
 
   private:
     struct DeviceBuffers;

@@ -18,6 +18,7 @@ namespace {
 constexpr uint32_t kSymbols = 256;
 constexpr uint32_t kBlock = 16;                  // symbols per block sum
 constexpr uint32_t kHeader = 4;                  // PACKET_HEADER_LENGTH, src/gpu.h:14
+constexpr uint32_t kPacketBytes = 8192;          // UNCOMPRESSED_PACKET_SIZE, src/gpu.h:13
 
 inline uint32_t lowbit(uint32_t i) { return i & (0u - i); }
 inline uint32_t clz16(uint32_t v) { return v ? static_cast<uint32_t>(__builtin_clz(v)) - 16u : 16u; }
@@ -199,7 +200,12 @@ uint16_t arDecompress(const uint8_t *fpIn, const uint16_t inSize, uint8_t *fpOut
     model.unpack(r.ranges, cumProb);
     const uint32_t clen = static_cast<uint32_t>(fpIn[0]) | (static_cast<uint32_t>(fpIn[1]) << 8);
     const uint32_t ulen = static_cast<uint32_t>(fpIn[2]) | (static_cast<uint32_t>(fpIn[3]) << 8);
-    const uint32_t readable = clen > inSize ? clen : inSize;
+    // The reference ignores inSize and trusts the packet's own header (it reads whatever follows a
+    // short packet and writes ulen bytes whatever the caller's buffer holds).  Here reads stop at the
+    // caller's inSize when it is given (at clen otherwise), and a packet that claims more than one
+    // packet's worth of output (> 8192 bytes) is refused -- the same guards as DecoderLane::open.
+    if (ulen > kPacketBytes) return 0;
+    const uint32_t readable = inSize ? inSize : clen;
     BitSource source{fpIn + kHeader, fpIn + (readable < kHeader ? kHeader : readable)};
     uint32_t lo = 0, hi = 0xFFFFu;
     uint32_t code = source.take(16);             // initializeDecoder :582-603

@@ -32,7 +32,9 @@ extern "C" {
 #endif
 
 #define GPUAR_PACKET_BYTES        8192u  /* UNCOMPRESSED_PACKET_SIZE, src/gpu.h:13 */
+#ifndef GPUAR_SLOT_BYTES                 /* only tests/lane_emulation.cpp ever overrides it (to drive a lane into overflow) */
 #define GPUAR_SLOT_BYTES          8704u  /* COMPRESSED_PACKET_SIZE,   src/gpu.h:12 */
+#endif
 #define GPUAR_PACKET_HEADER_BYTES 4u     /* PACKET_HEADER_LENGTH,     src/gpu.h:14 */
 
 /* Error codes returned by the gpuar_hip_* calls (0 = ok).  Positive values

@@ -106,3 +106,92 @@ def test_gpu_cli_index_trailer_and_bulk_reads(tmp_path):
     (tmp_path / "cut.gip").write_bytes(a[:len(a) - 100])
     r = run("d", f"--in={tmp_path / 'cut.gip'}", f"--out={tmp_path / 'cut.out'}")
     assert r.returncode == 1 and "file" in r.stderr.lower()
+
+
+def test_gpu_cli_file_over_4gib(tmp_path):
+    """a > 4 GiB file through `gpuar c` / `gpuar d` on the GPU path.  The input
+    is a sparse file of zeros with a few islands of data (so it costs no disk on the way in): the header must
+    carry the size as a u64 (the reference's u32 at src/file_header.hpp:50-51,63-71 would wrap), the stream
+    must be the concatenation of the per-packet oracle outputs at the islands, and the file must decode back."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = (4 << 30) + (64 << 20) + 4321                    # ragged, > 2^32
+    src, gip, back = tmp_path / "big.dat", tmp_path / "big.gip", tmp_path / "big.back"
+    islands = {0: synth.text(1, 3 * 8192), (1 << 32) - 8192: synth.uniform(2, 3 * 8192), n - 4321 - 8192: synth.zipf(3, 8192 + 4321)}
+    with open(src, "wb") as f:
+        f.truncate(n)
+        for at, data in islands.items():
+            f.seek(at)
+            f.write(data.tobytes())
+    r = run("c", f"--in={src}", f"--out={gip}")
+    assert r.returncode == 0, r.stderr
+    blob = gip.read_bytes()
+    assert int.from_bytes(blob[4:12], "little") == n and n > 0xFFFFFFFF          # u64 size field in use
+    assert int.from_bytes(blob[12:20], "little") == len(blob)
+    npk = (n + 8191) // 8192
+    from oracle import oracle as O
+    zero_pkt = O.best().encode_packet(bytes(8192))
+    assert len(zero_pkt) == 210
+    # first packets = the text island, then zero packets
+    want_head = O.best().encode_stream(islands[0]).tobytes()
+    assert blob[20:20 + len(want_head)] == want_head
+    assert blob[20 + len(want_head):20 + len(want_head) + 210] == zero_pkt
+    # the tail island (last two packets, the very last one short) closes the file
+    want_tail = O.best().encode_stream(islands[n - 4321 - 8192]).tobytes()
+    assert blob[-len(want_tail):] == want_tail
+    assert len(blob) > 20 + (npk - 8) * 210
+    del blob
+    r = run("d", f"--in={gip}", f"--out={back}")
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(back) == n
+    with open(back, "rb") as f:
+        for at, data in islands.items():
+            f.seek(at)
+            assert f.read(data.size) == data.tobytes(), at
+        f.seek(1 << 31)
+        assert f.read(1 << 20) == bytes(1 << 20)
+    # whole-file check without holding 4 GiB in memory: md5 in 64 MiB pieces against the sparse source
+    ha, hb = hashlib.md5(), hashlib.md5()
+    with open(src, "rb") as a, open(back, "rb") as b:
+        while True:
+            x, y = a.read(64 << 20), b.read(64 << 20)
+            if not x and not y:
+                break
+            ha.update(x)
+            hb.update(y)
+    assert ha.hexdigest() == hb.hexdigest()
+
+
+def test_gpu_cli_batch_that_is_not_a_multiple_of_64(tmp_path):
+    """--gpus=2 --batch=100: per-device shares are whole wavefronts (multiples of 64 packets), so the batch is
+    rounded down to 64 and nothing outgrows its buffers; output identical to the default run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, g1, g2, back = tmp_path / "in.dat", tmp_path / "one.gip", tmp_path / "two.gip", tmp_path / "back.dat"
+    data = synth.uniform(15, 777 * 8192 + 55)
+    data.tofile(src)
+    env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
+    assert run("c", f"--in={src}", f"--out={g1}").returncode == 0
+    r = subprocess.run([CLI, "c", f"--in={src}", f"--out={g2}", "--gpus=2", "--batch=100"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert g1.read_bytes() == g2.read_bytes()
+    r = subprocess.run([CLI, "d", f"--in={g2}", f"--out={back}", "--gpus=2", "--batch=100"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data.tobytes()
+
+
+def test_gpu_cli_decodes_files_with_the_references_uninitialised_header_bytes(tmp_path):
+    """A .gip written by the reference has garbage in header bytes 3, 8-11, 16-19; the GPU path must write
+    exactly the bytes the packets hold (last packet short), as --host does."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_cli_host import reference_style_header
+    src, gip, ref_gip, back = tmp_path / "in.dat", tmp_path / "a.gip", tmp_path / "ref.gip", tmp_path / "back.dat"
+    data = synth.text(12, 70 * 8192 + 777)
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={gip}").returncode == 0
+    ref_gip.write_bytes(reference_style_header(gip.read_bytes()))
+    r = run("d", f"--in={ref_gip}", f"--out={back}")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data.tobytes()
+    assert f"Uncompressed file size {data.size} bytes" in r.stdout

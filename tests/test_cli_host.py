@@ -140,3 +140,62 @@ def test_index_trailer_is_a_pure_suffix(cli, tmp_path):
     assert len(e) == 20 + 28 and int.from_bytes(e[12:20], "little") == 20
     assert run(cli, "d", "--host", f"--in={tmp_path / 'e.gip'}", f"--out={tmp_path / 'e.back'}").returncode == 0
     assert (tmp_path / "e.back").read_bytes() == b""
+
+
+def test_config0_full_64mib_through_the_products_cpu_compressor(cli, tmp_path):
+    """BASELINE.json configs[0]: data/random_64m.dat (stand-in: uniform(42), 64 MiB) encoded and decoded by
+    the product's own CPUCompressor (`gpuar --host`), md5-checked as /root/reference/README.md:12-29 does.
+    Packet stream md5 = what the reference's --host CLI wrote for the same bytes."""
+    s = [s for s in SURVEY["streams"] if s.get("slow")][0]
+    assert s["n"] == 64 << 20 and s["stream_md5"] == "c01b5d124681f6fc7264574e57548cdb"
+    src, gip, back = tmp_path / "random_64m.dat", tmp_path / "random_64m.gip", tmp_path / "random_64m.back"
+    synth.generate(s["kind"], s["seed"], s["n"]).tofile(src)
+    r = run(cli, "c", "--host", "--threads=0", f"--in={src}", f"--out={gip}")
+    assert r.returncode == 0, r.stderr
+    blob = gip.read_bytes()
+    assert len(blob) == s["gip_bytes"] == 67648304
+    assert int.from_bytes(blob[4:8], "little") == s["n"] and int.from_bytes(blob[12:16], "little") == s["gip_bytes"]
+    assert hashlib.md5(blob[20:]).hexdigest() == s["stream_md5"]
+    del blob
+    r = run(cli, "d", "--host", "--threads=0", f"--in={gip}", f"--out={back}")
+    assert r.returncode == 0, r.stderr
+    assert hashlib.md5(back.read_bytes()).hexdigest() == s["input_md5"] == "c9f0253b284172e8c4456be3234de256"
+
+
+def reference_style_header(blob: bytes) -> bytes:
+    """What the reference's writer leaves in a .gip header: only the low 4 bytes of each size are set,
+    bytes 3, 8-11 and 16-19 are whatever was on its stack (src/file_header.hpp:31-36)."""
+    h = bytearray(blob[:20])
+    h[3] = 0x5A
+    h[8:12] = b"\xde\xad\xbe\xef"
+    h[16:20] = b"\x13\x37\xc0\xde"
+    return bytes(h) + blob[20:]
+
+
+def test_host_decodes_files_with_the_references_uninitialised_header_bytes(cli, tmp_path):
+    src, gip, ref_gip, back = tmp_path / "in.dat", tmp_path / "a.gip", tmp_path / "ref.gip", tmp_path / "back.dat"
+    data = synth.text(12, 3 * 8192 + 777)
+    data.tofile(src)
+    assert run(cli, "c", "--host", f"--in={src}", f"--out={gip}").returncode == 0
+    ref_gip.write_bytes(reference_style_header(gip.read_bytes()))
+    r = run(cli, "d", "--host", f"--in={ref_gip}", f"--out={back}")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data.tobytes()
+    assert f"Uncompressed file size {data.size} bytes" in r.stdout
+
+
+def test_host_decode_streams_in_windows(cli, tmp_path):
+    """--host d walks the stream in windows of 4096 packets (bounded memory): a file longer than one
+    window, with a ragged tail, with and without the index trailer."""
+    src, gip, idx, back = tmp_path / "in.dat", tmp_path / "a.gip", tmp_path / "i.gip", tmp_path / "back.dat"
+    data = synth.zipf(5, (4096 + 300) * 8192 + 99)
+    data.tofile(src)
+    assert run(cli, "c", "--host", "--threads=0", f"--in={src}", f"--out={gip}").returncode == 0
+    assert run(cli, "c", "--host", "--threads=0", "--index", f"--in={src}", f"--out={idx}").returncode == 0
+    for f in (gip, idx):
+        assert run(cli, "d", "--host", "--threads=0", f"--in={f}", f"--out={back}").returncode == 0
+        assert hashlib.md5(back.read_bytes()).hexdigest() == hashlib.md5(data.tobytes()).hexdigest()
+    cut = tmp_path / "cut.gip"
+    cut.write_bytes(gip.read_bytes()[:-50])
+    r = run(cli, "d", "--host", "--threads=0", f"--in={cut}", f"--out={back}")
+    assert r.returncode == 1

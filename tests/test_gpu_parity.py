@@ -35,6 +35,23 @@ def oracle():
     return O.best()
 
 
+def oracle_slots(codec, data: np.ndarray):
+    """The packet slots the oracle says `data` codes to: (slots[npk, 8704] zero-padded, clen[npk], total bytes).
+    Built from the best oracle on the box (the reference's own codec when oracle/_ref is there)."""
+    stream = codec.encode_stream(data)
+    npk = (data.size + 8191) // 8192
+    slots = np.zeros((max(npk, 1), 8704), dtype=np.uint8)
+    lens = np.zeros(npk, dtype=np.int64)
+    off = 0
+    for p in range(npk):
+        c = int(stream[off]) | (int(stream[off + 1]) << 8)
+        slots[p, :c] = stream[off:off + c]
+        lens[p] = c
+        off += c
+    assert off == stream.size
+    return slots, lens, int(stream.size)
+
+
 def gpu_stream(H, data: np.ndarray):
     """encode + compact on the GPU; returns (stream bytes, offsets, slots tensor, npk)."""
     npk = H.packet_count(data.size)
@@ -92,15 +109,15 @@ def test_device_generators_match_numpy(H):
 
 @pytest.mark.parametrize("kind", ["uniform", "zipf", "text", "zeros"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 8191, 8192, 8193, 64 * 8192, 64 * 8192 + 1, 200 * 8192 + 4097])
-def test_slots_equal_oracle(H, oracle_port, kind, n):
+def test_slots_equal_oracle(H, oracle, kind, n):
     data = synth.generate(kind, 21, n)
-    want_slots, total = oracle_port.encode_slots(data)
+    want_slots, lens, total = oracle_slots(oracle, data)
     d_slots = H.encode(torch.from_numpy(data).cuda())
     got = d_slots.cpu().numpy()
     npk = H.packet_count(n)
     for p in range(npk):
-        clen = int(want_slots[p * 8704]) | (int(want_slots[p * 8704 + 1]) << 8)
-        assert np.array_equal(got[p * 8704:p * 8704 + clen], want_slots[p * 8704:p * 8704 + clen]), (kind, n, p)
+        clen = int(lens[p])
+        assert np.array_equal(got[p * 8704:p * 8704 + clen], want_slots[p, :clen]), (kind, n, p)
     back = H.decode(d_slots, npk)[:n].cpu().numpy()
     assert np.array_equal(back, data)
     assert H.status() == 0
@@ -213,7 +230,7 @@ def test_compaction_offsets_beyond_4gib(H):
     assert H.status() == 0
 
 
-def test_many_mixed_packets_against_oracle(H, oracle_port):
+def test_many_mixed_packets_against_oracle(H, oracle):
     """2048 packets, every one from a different source model (uniform, k-symbol, geometric, long
     runs, ramps, near-midpoint pairs, constant): slot-for-slot equality with the oracle, then decode."""
     rng = np.random.default_rng(20261003)
@@ -238,14 +255,13 @@ def test_many_mixed_packets_against_oracle(H, oracle_port):
             view[:] = int(rng.integers(0, 256))
         else:
             view[:] = np.sort(rng.integers(0, 256, 8192, dtype=np.uint8))
-    want, total = oracle_port.encode_slots(data)
+    want, want_len, total = oracle_slots(oracle, data)
     d_slots = H.encode(torch.from_numpy(data).cuda())
     got = d_slots.cpu().numpy()
-    want_len = want.reshape(npk, 8704)[:, 0].astype(np.int64) | (want.reshape(npk, 8704)[:, 1].astype(np.int64) << 8)
     got_len = got.reshape(npk, 8704)[:, 0].astype(np.int64) | (got.reshape(npk, 8704)[:, 1].astype(np.int64) << 8)
     assert np.array_equal(want_len, got_len)
     mask = np.arange(8704)[None, :] < want_len[:, None]
-    assert np.array_equal(got.reshape(npk, 8704)[mask], want.reshape(npk, 8704)[mask])
+    assert np.array_equal(got.reshape(npk, 8704)[mask], want[mask])
     d_stream, d_off = H.compact(d_slots, npk)
     assert int(d_off[-1].item()) == total
     assert np.array_equal(H.decode(d_slots, npk).cpu().numpy(), data)
@@ -276,3 +292,78 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
     assert abs(d["compression_ratio"] - 1.00804) < 1e-3
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+
+
+def _self_launched_bench(extra, tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher around it: bench.py must start its two ranks itself
+    (fresh child processes, before it touches the GPU) and relay rank 0's JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-small-config", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    d = _self_launched_bench(["--gib-per-gpu", "0.25"], tmp_path)
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True and d["device_status"] == 0
+    assert abs(d["compression_ratio"] - 1.00804) < 1e-3
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 0.25 * 1.073741824) < 1e-6    # both ranks' bytes over the time
+
+
+def test_bench_strong_scaling_splits_one_stream(tmp_path):
+    """configs[3] in miniature: a fixed total split into contiguous packet ranges, one per rank."""
+    d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5"], tmp_path)
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 0.5 * 1.073741824) < 1e-6           # the total, not per rank
+    assert abs(d["compression_ratio"] - 1.00804) < 1e-3
+
+
+def _shard_at_true_offset(H, oracle, kind, seed, offset, n, ratio_band):
+    """One rank's shard of a BASELINE config, generated on the device at its true offset in the global
+    stream: encode, compact, decode both ways; the whole shard round-trips, and three windows of 64 packets
+    (first, middle, last) are byte-equal to what the oracle makes of the same bytes generated on the host."""
+    d_in = H.generate(kind, seed, n, offset=offset)
+    npk = H.packet_count(n)
+    d_slots = H.encode(d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    total = int(d_off[-1].item())
+    assert ratio_band[0] < total / n < ratio_band[1]
+    d_back = H.decode(d_slots, npk)
+    assert torch.equal(d_back[:n], d_in)
+    del d_back, d_slots
+    d_back2 = H.decode_stream(d_stream, d_off, npk)
+    assert torch.equal(d_back2[:n], d_in)
+    del d_back2
+    assert H.status() == 0
+    for p0 in (0, npk // 2 - 32, npk - 64):
+        host = synth.generate(kind, seed, 64 * 8192, offset=offset + p0 * 8192)
+        assert np.array_equal(d_in[p0 * 8192:(p0 + 64) * 8192].cpu().numpy(), host), (kind, p0)      # same bytes on both sides
+        want = oracle.encode_stream(host)
+        got = d_stream[int(d_off[p0].item()):int(d_off[p0 + 64].item())].cpu().numpy()
+        assert got.size == want.size and np.array_equal(got, want), (kind, p0)
+
+
+def test_config3_last_rank_of_uniform_8gib_over_8_gpus(H, oracle):
+    """BASELINE.json configs[3]: uniform(42) 8 GiB sharded over 8 GPUs -- rank 7 codes bytes [7 GiB, 8 GiB)."""
+    from gpuar_amd import sharding
+    off, n = sharding.plan_shards(8 << 30, 8)[7]
+    assert (off, n) == (7 << 30, 1 << 30)
+    _shard_at_true_offset(H, oracle, "uniform", 42, off, n, (1.0075, 1.0085))
+
+
+def test_config4_last_rank_of_zipf_64gib_over_8_gpus(H, oracle):
+    """BASELINE.json configs[4]: zipf(1) 64 GiB over 8 GPUs -- rank 7 codes bytes [56 GiB, 64 GiB), 8 GiB per GPU."""
+    from gpuar_amd import sharding
+    off, n = sharding.weak_shard(8 << 30, 7)
+    assert (off, n) == (56 << 30, 8 << 30)
+    _shard_at_true_offset(H, oracle, "zipf", 1, off, n, (0.78, 0.80))

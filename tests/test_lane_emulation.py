@@ -42,6 +42,23 @@ def emu():
     return lib
 
 
+@pytest.fixture(scope="session")
+def emu_small_slots():
+    """The same emulation built with 1024-byte slots, so ordinary data drives CoderLane into overflow."""
+    out_dir = os.path.join(HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liblane_emulation_slot1024.so")
+    srcs = [os.path.join(HERE, "lane_emulation.cpp"), os.path.join(ROOT, "gpuar_amd", "csrc", "lane_codec.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000",
+                               "-fconstexpr-loop-limit=1000000", "-Wno-unknown-pragmas", "-DGPUAR_SLOT_BYTES=1024u",
+                               "-I", os.path.join(ROOT, "include"), "-o", so, srcs[0]])
+    lib = C.CDLL(so)
+    lib.emu_encode_slots.restype = C.c_int
+    lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
+    return lib
+
+
 def emu_encode(lib, data: np.ndarray):
     npk = (data.size + 8191) // 8192
     slots = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
@@ -117,3 +134,27 @@ def test_lane_decoder_survives_garbage(emu):
         flagged += emu.emu_decode_stream(blob.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), 1, out.ctypes.data_as(u8p))
         assert np.all(out[8192:] == 0xA5)
     assert flagged > 0          # impossible lengths and out-of-model code values are reported
+
+
+def test_slot_overflow_is_flagged_and_contained(emu_small_slots, port_oracle):
+    """GPUAR_STATUS_SLOT_OVERFLOW path (CoderLane::put clamp + finish): a packet that outgrows its slot is
+    reported, its stores never leave the slot, its header says clen = slot size, and the bytes that did fit
+    are the true prefix of the packet.  A packet that fits next to it is untouched by the neighbour's overflow."""
+    slot = 1024
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 256, 8192, dtype=np.uint8)          # ~8250 bytes of output: overflows a 1024-byte slot
+    small = np.zeros(8192, dtype=np.uint8)                    # 210 bytes: fits
+    data = np.concatenate([big, small, big[:5000]])
+    guard = 64
+    buf = np.full(3 * slot + guard, 0xA5, dtype=np.uint8)
+    ov = emu_small_slots.emu_encode_slots(data.ctypes.data_as(u8p), data.size, buf.ctypes.data_as(u8p))
+    assert ov == 1
+    assert (buf[3 * slot:] == 0xA5).all()                      # nothing beyond the last slot
+    want0 = port_oracle.encode_packet(big.tobytes())
+    want1 = port_oracle.encode_packet(small.tobytes())
+    # packet 0 overflowed: clen clamped to the slot size, ulen kept, the body up to the last dword is the true prefix
+    assert int(buf[0]) | (int(buf[1]) << 8) == slot and int(buf[2]) | (int(buf[3]) << 8) == 8192
+    assert buf[4:slot - 4].tobytes() == want0[4:slot - 4]
+    # packet 1 fits and is exact, although its neighbours overflowed
+    assert buf[slot:slot + len(want1)].tobytes() == want1
+    assert int(buf[2 * slot]) | (int(buf[2 * slot + 1]) << 8) == slot
