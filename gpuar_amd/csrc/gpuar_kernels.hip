@@ -33,6 +33,7 @@
 namespace gpuar {
 
 __constant__ RecipTable g_recip = RecipTable();
+__constant__ DecodeConstTable g_decode = DecodeConstTable();
 __device__ uint32_t g_status = 0;
 __device__ uint32_t g_cu_ticket[2048];      // one arrival counter per CU (XCC, SE, SH, CU), see encode_kernel
 
@@ -294,6 +295,204 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 // Decode: replaces garDecompress + arDecompress (:916-934, 848-892)
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// The symbol step of the decoder, scheduled by hand for a wavefront that is ALONE on its SIMD
+// (the per-packet model pins 36 KiB of LDS per wavefront, four wavefronts per CU).
+//
+// What tools/lat_probe.hip measures for such a wavefront (profiles/r02_lat_probe.txt): every vector
+// instruction costs one issue slot of 4.2-4.7 cycles whether or not it depends on its predecessor;
+// `s_nop 0` costs a whole slot (4 cycles), `s_nop 1` two; a scalar instruction costs a slot as well;
+// ds_read_b128 comes back after ~65 cycles and holds the issue port ~12, ds_write_b128 ~20.  So the
+// step is priced in SLOTS, and the two LDS round trips are free exactly when ~15 independent
+// instructions sit behind each read.  The compiler's own schedule of lane_codec.h's step_symbol
+// spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane mask it
+// writes); the two statements below spend 103 and leave the stream reader (skip(), ~13 slots with
+// its refill branch) to the compiler, because the reader's global load has to stay visible to the
+// compiler's s_waitcnt bookkeeping.
+//
+//   statement A : R0 = off*total + total - 1; depths 0 and 1 (registers); write-back of the previous
+//                 symbol's low record; READ #1 (mid record) issued; register nodes bumped
+//   (C++)       : skip() of the previous symbol's bits, peek()           <- shadow of read #1
+//   statement BC: mid record: 3 decisions; READ #2 (low record) issued; mid record rebuilt and
+//                 written back                                            <- shadow of read #2
+//                 low record: 3 decisions, W = cnt*range, interval narrowed and renormalised,
+//                 low record rebuilt into the `owed` registers
+//   (C++)       : off = (off - dn : window) << n, the symbol joins the output word
+//
+// Lane masks: v_sub_co writes "went left" as its borrow; v_min keeps the remainder; the mask is
+// read two or more instructions later (path add-with-carry, selects of the next node and of the
+// record rebuild).  The four 16-byte LDS operands need aligned register quads and are pinned
+// (v200-v215); everything else is allocated by the compiler.  Results are those of
+// DecoderLane::step_symbol instruction for instruction (same integers), which the CPU tests pin
+// against the oracle; the GPU parity tests then compare this path with the oracle directly.
+// ---------------------------------------------------------------------------
+#if defined(GPUAR_EXP_NOWAIT)
+#define GPUAR_EXP_WAIT1 ""
+#define GPUAR_EXP_WAIT2 ""
+#elif defined(GPUAR_EXP_NOWAIT1)
+#define GPUAR_EXP_WAIT1 ""
+#define GPUAR_EXP_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
+#elif defined(GPUAR_EXP_NOWAIT2)
+#define GPUAR_EXP_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
+#define GPUAR_EXP_WAIT2 ""
+#else
+#define GPUAR_EXP_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
+#define GPUAR_EXP_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
+#endif
+#define GPUAR_DUMMY4 "v_add_u32 %[t0], 1, %[t0]\n\tv_add_u32 %[t1], 1, %[t1]\n\tv_add_u32 %[t0], 1, %[t0]\n\tv_add_u32 %[t1], 1, %[t1]\n\t"
+#define GPUAR_DUMMY16 GPUAR_DUMMY4 GPUAR_DUMMY4 GPUAR_DUMMY4 GPUAR_DUMMY4
+#if defined(GPUAR_EXP_ADD_A)
+#define GPUAR_EXP_PAD_A GPUAR_DUMMY16
+#else
+#define GPUAR_EXP_PAD_A ""
+#endif
+#if defined(GPUAR_EXP_ADD_B)
+#define GPUAR_EXP_PAD_B GPUAR_DUMMY16
+#else
+#define GPUAR_EXP_PAD_B ""
+#endif
+#define GPUAR_SDWA_W0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+#define GPUAR_SDWA_W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+#define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+
+// One symbol of the hand-scheduled decoder (see above).  Uses decode_wave's locals by name.
+#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_MUL, K_SHIFT, NP_OUT)                                                             \
+    {                                                                                                               \
+        uint32_t R0, R, np, am, t0, t1, t2; \
+        unsigned long long m0, m1; \
+        asm volatile( \
+            "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
+            "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
+            "v_add_u32 %[R0], -1, %[R0]\n\t" /* off*total + total - 1 */ \
+            "v_sub_co_u32 %[t1], %[m0], %[R0], %[t0]\n\t" /* borrow = went left at depth 0 */ \
+            "v_min_u32 %[R], %[R0], %[t1]\n\t" \
+            "v_cndmask_b32 %[t2], %[h1], %[h0], %[m0]\n\t" /* the depth-1 node on the path */ \
+            "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
+            "v_sub_co_u32 %[t1], %[m1], %[R], %[t0]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_cndmask_b32 %[np], 0, 2, %[m0]\n\t" \
+            "v_addc_co_u32 %[np], vcc, %[np], 0, %[m1]\n\t" /* complemented top two symbol bits */ \
+            "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
+            "ds_read_b128 v[200:203], %[am]\n\t" /* READ #1: mid record ... */ \
+            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* ... and the previous symbol's low record behind it */ \
+            "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
+            "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
+            "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
+            "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
+            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
+              "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
+            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
+              "v"(o0), "v"(o1), "v"(o2), "v"(o3) \
+            : "vcc", "memory"); \
+         /* shadow of read #1: the stream reader catches up with the previous symbol */ \
+        dec.skip(dec.owed_bits); \
+        const uint32_t window = dec.peek(); \
+        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e; \
+        unsigned long long ma, mc, mj; \
+        asm volatile( \
+            GPUAR_EXP_PAD_A GPUAR_EXP_WAIT1 /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
+         /* ---- mid record: w0 = a | bR << 16, w1 = - | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
+            "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
+            "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_sub_u32 %[t3], %[off], %[rng]\n\t" /* off >= range: no symbol owns this code value */ \
+            "v_cndmask_b32 %[bw], v200, v201, %[ma]\n\t" /* chosen child in the high half */ \
+            "v_cndmask_b32 %[cc], v202, v203, %[ma]\n\t" /* its two children */ \
+            "v_mul_u32_u24_sdwa %[t0], %[bw], %[rng]" GPUAR_SDWA_W1 \
+            "v_sub_co_u32 %[t1], vcc, %[R], %[t0]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_min_u32 %[bad], %[bad], %[t3]\n\t" \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
+            "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
+            "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
+            "v_sub_co_u32 %[t1], %[mc], %[R], %[t0]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" /* +1 for bL/bR if left at the middle decision */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[np], 10, %[col]\n\t" \
+            "ds_read_b128 v[212:215], %[oaddr] offset:4096\n\t" /* READ #2: low record */ \
+         /* ---- mid record rebuilt in the shadow of read #2 */ \
+            "v_add_u32 %[bw], %[bw], %[t3]\n\t" \
+            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
+            "v_add_u32 %[cc], %[cc], %[t2]\n\t" \
+            "v_cndmask_b32 v208, %[bw], v200, %[ma]\n\t" \
+            "v_cndmask_b32 v209, v201, %[bw], %[ma]\n\t" \
+            "v_cndmask_b32 v210, %[cc], v202, %[ma]\n\t" \
+            "v_cndmask_b32 v211, v203, %[cc], %[ma]\n\t" \
+            "v_addc_co_u32 v208, %[mj], v208, 0, %[ma]\n\t" \
+            "ds_write_b128 %[am], v[208:211]\n\t" \
+            GPUAR_EXP_WAIT2 GPUAR_EXP_PAD_B \
+         /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
+            "v_mul_u32_u24_sdwa %[pa], v212, %[rng]" GPUAR_SDWA_W0 \
+            "v_sub_co_u32 %[t1], %[ma], %[R], %[pa]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_mul_u32_u24_sdwa %[ps], v213, %[rng]" GPUAR_SDWA_W0 \
+            "v_cndmask_b32 %[bw], v212, v213, %[ma]\n\t" \
+            "v_cndmask_b32 %[cc], v214, v215, %[ma]\n\t" \
+            "v_mul_u32_u24_sdwa %[pb], %[bw], %[rng]" GPUAR_SDWA_W1 \
+            "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_sub_u32 %[t3], %[ps], %[pa]\n\t" \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
+            "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
+            "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
+            "v_sub_co_u32 %[t1], %[mc], %[R], %[pc]\n\t" \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_cndmask_b32 %[t3], %[t3], %[pa], %[ma]\n\t" /* width of the depth-6 subtree on the path, scaled */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_sub_u32 %[t3], %[t3], %[pb]\n\t" \
+            "v_cndmask_b32 %[t3], %[t3], %[pb], vcc\n\t" /* ... of the depth-7 pair */ \
+            "v_sub_u32 %[t3], %[t3], %[pc]\n\t" \
+            "v_cndmask_b32 %[t3], %[t3], %[pc], %[mc]\n\t" /* W = cnt(symbol) * range */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" /* all eight complemented symbol bits */ \
+         /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
+            "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
+            "v_add_u32 %[t1], %[t0], %[t3]\n\t" /* cumHi * range */ \
+            "v_mul_hi_u32 %[dn], %[t0], %[mul]\n\t" \
+            "v_mul_hi_u32 %[t1], %[t1], %[mul]\n\t" \
+            "v_lshrrev_b32 %[dn], %[shift], %[dn]\n\t" \
+            "v_lshrrev_b32 %[t1], %[shift], %[t1]\n\t" \
+            "v_add_u32 %[a], %[lo], %[dn]\n\t" /* new lo */ \
+            "v_sub_u32 %[wd], %[t1], %[dn]\n\t" /* new hi - new lo + 1 */ \
+            "v_add3_u32 %[h], %[a], %[wd], -1\n\t" /* new hi */ \
+            "v_xor_b32_sdwa %[kff], %[a], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+            "v_bfi_b32 %[t2], %[a], %[h], -1\n\t" /* ~a | h */ \
+            "v_ffbh_u32 %[e], %[kff]\n\t" /* agreeing MSBs */ \
+            "v_sub_u32 %[t3], 15, %[e]\n\t" \
+            "v_alignbit_b32 %[t2], %[t2], -1, %[t3]\n\t" \
+            "v_ffbh_u32 %[t2], %[t2]\n\t" /* underflow run */ \
+            "v_add_u32 %[n], %[e], %[t2]\n\t" \
+            "v_lshlrev_b32 %[a], %[n], %[a]\n\t" \
+            "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
+            "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
+         /* ---- low record rebuilt -> owed (written back by the next statement A) */ \
+            "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" \
+            "v_add_u32 %[bw], %[bw], %[t3]\n\t" \
+            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
+            "v_add_u32 %[cc], %[cc], %[t2]\n\t" \
+            "v_cndmask_b32 v204, %[bw], v212, %[ma]\n\t" \
+            "v_cndmask_b32 v205, v213, %[bw], %[ma]\n\t" \
+            "v_cndmask_b32 v206, %[cc], v214, %[ma]\n\t" \
+            "v_cndmask_b32 v207, v215, %[cc], %[ma]\n\t" \
+            "v_addc_co_u32 v204, %[mj], v204, 0, %[ma]\n\t" \
+            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */ \
+            : [R] "+v"(R), [np] "+v"(np), [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [kff] "+v"(kff), [bad] "+v"(bad_min), \
+              [oaddr] "=&v"(oaddr), [dn] "=&v"(dn), [n] "=&v"(n), [bw] "=&v"(bw), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), \
+              [t2] "=&v"(t2), [t3] "=&v"(t3), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), [a] "=&v"(a), \
+              [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), \
+              "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
+            : [R0] "v"(R0), [off] "v"(dec.off), [col] "v"(col_lds), [am] "v"(am), [k64k] "v"(k64k), \
+              [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)) \
+            : "vcc", "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"); \
+        dec.off = static_cast<uint32_t>((((static_cast<uint64_t>(dec.off - dn) << 32) | window) << n) >> 32); \
+        dec.owed_bits = n; \
+        NP_OUT = np;                                                                                                \
+    }
+
 // `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit
 __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
                                             uint8_t *out, bool live) {
@@ -308,33 +507,77 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     // dead lane of the last wavefront, the file's short last packet -- sits the block out with its
     // state untouched (plain SIMT divergence), so one such lane no longer slows the other 63 down.
     uint32_t i = 0;
+
+    // ---- state of the hand-scheduled step ----
+    const uint32_t col_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(col));   // LDS byte address of this lane's column
+    register uint32_t q0 asm("v200");          // mid record as read (statement A issues the read, BC waits for it)
+    register uint32_t q1 asm("v201");
+    register uint32_t q2 asm("v202");
+    register uint32_t q3 asm("v203");
+    register uint32_t o0 asm("v204");          // low record of the previous symbol, rebuilt, not yet written back
+    register uint32_t o1 asm("v205");
+    register uint32_t o2 asm("v206");
+    register uint32_t o3 asm("v207");
+    o0 = dec.model.owed.w0, o1 = dec.model.owed.w1, o2 = dec.model.owed.w2, o3 = dec.model.owed.w3;
+    uint32_t oaddr = col_lds + dec.model.owed.rec - SubtreeModel<10>::kLowBase;      // the write carries offset:4096
+    // min over the symbols of (off - range) mod 2^32: a value below 0xFFFF0000 means that some symbol met
+    // off >= range, a code value no symbol owns (range <= 2^16, so off < range wraps to >= 0xFFFF0000)
+    uint32_t bad_min = 0xFFFFFFFFu;
+    uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
+    const uint32_t k64k = 0x10000u;
+
+    // The per-symbol constants come as ONE 64-byte scalar load per group of four symbols, issued a whole
+    // group ahead into the register set the group after next will read (two sets, taken in turn: no
+    // copies).  One load in flight at most matters: a scalar load counts in lgkmcnt like the LDS
+    // operations but may return out of order, so the waits of the symbol step are all of the form
+    // "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" -- satisfied as soon as the read
+    // is back whether or not the scalar load is.  (With lgkmcnt(0) waits, or with the model total needed
+    // from a load issued in the same group, every fourth symbol sat out a scalar-cache miss: 175 of 830
+    // cycles per symbol.)
+    typedef uint32_t ConstGroup __attribute__((ext_vector_type(16)));       // {mul, shift, total, total - 1} x 4
+    const ConstGroup *const_groups = reinterpret_cast<const ConstGroup *>(g_decode.c);
+    constexpr uint32_t kLastGroup = kPacket / 4u - 1u;
     for (; i + 64u <= len_max; i += 64u) {
-        if (i + 64u <= dec.ulen) {
+        if (i + 64u <= dec.ulen) {                           // this lane decodes the whole block
             uint32_t block[16];
+            ConstGroup ka = const_groups[i >> 2];
 #pragma unroll 1
-            for (uint32_t g = 0; g < 16u; ++g) {
-                const uint32_t at = i + 4u * g;                  // wave-uniform
-                Recip rc[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) rc[j] = g_recip.r[at + j];
-                uint32_t word = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) word |= dec.step_symbol(at + j, rc[j]) << (8u * j);
-                block[g] = word;                                 // uniform index: register-indexed move
+            for (uint32_t g = 0; g < 16u; g += 2u) {
+                const uint32_t group = (i >> 2) + g;         // wave-uniform
+                // the next group's constants are asked for AFTER the first symbol of this group: by then this
+                // group's own load (issued a group ago) has long landed, so the compiler's wait for it (a scalar
+                // load can only be waited for with lgkmcnt(0)) does not catch the new one in flight
+                uint32_t word, np_out;
+                GPUAR_DECODE_SYMBOL(ka[2], ka[0], ka[1], np_out) word = np_out;
+                const ConstGroup kb = const_groups[group + 1u];
+                GPUAR_DECODE_SYMBOL(ka[6], ka[4], ka[5], np_out) word |= np_out << 8;
+                GPUAR_DECODE_SYMBOL(ka[10], ka[8], ka[9], np_out) word |= np_out << 16;
+                GPUAR_DECODE_SYMBOL(ka[14], ka[12], ka[13], np_out) word |= np_out << 24;
+                block[g] = ~word;                            // np holds the COMPLEMENTED symbol bits
+                GPUAR_DECODE_SYMBOL(kb[2], kb[0], kb[1], np_out) word = np_out;
+                ka = const_groups[group + 2u <= kLastGroup ? group + 2u : kLastGroup];
+                GPUAR_DECODE_SYMBOL(kb[6], kb[4], kb[5], np_out) word |= np_out << 8;
+                GPUAR_DECODE_SYMBOL(kb[10], kb[8], kb[9], np_out) word |= np_out << 16;
+                GPUAR_DECODE_SYMBOL(kb[14], kb[12], kb[13], np_out) word |= np_out << 24;
+                block[g + 1u] = ~word;
             }
             uint4 *dst = reinterpret_cast<uint4 *>(out + i);
 #pragma unroll
             for (uint32_t v = 0; v < 4; ++v) dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);
         }
     }
+    // hand the state back to the plain step (the tail below, finish())
+    dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
+    dec.model.owed.w0 = o0, dec.model.owed.w1 = o1, dec.model.owed.w2 = o2, dec.model.owed.w3 = o3;
+    dec.bad = dec.bad || bad_min < 0xFFFF0000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
     const uint32_t part_from = dec.ulen & ~63u;
     const uint32_t part_end = wave_max((dec.ulen & 63u) ? dec.ulen : 0u);
     const uint32_t part_begin = wave_max((dec.ulen & 63u) ? ~part_from : 0u) ^ 0xFFFFFFFFu;   // min over those lanes
     for (i = part_begin; i < part_end; ++i) {
-        const Recip rc = g_recip.r[i];
-        if (i >= part_from && i < dec.ulen) dec.step(i, rc, out);
+        const DecodeConst k = g_decode.c[i];
+        if (i >= part_from && i < dec.ulen) dec.step(i, k, out);
     }
     if (live) {
         dec.finish(out);

@@ -20,6 +20,7 @@ namespace gip {
 namespace {
 
 const gpuar::RecipTable kRecip = gpuar::RecipTable();
+const gpuar::DecodeConstTable kDecode = gpuar::DecodeConstTable();
 constexpr size_t kBatchPackets = 4096;   // 32 MiB of input per batch
 
 // one packet through the same three lane programs the GPU's encoder wavefronts run
@@ -48,7 +49,7 @@ size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
     gpuar::DecoderLane<4> dec;
     const size_t readable = static_cast<size_t>(limit - pkt);
     dec.open(records, pkt, 0, readable < 0x7FFFFFFFu ? static_cast<uint32_t>(readable) : 0x7FFFFFFFu, true);
-    for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], out);
+    for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kDecode.c[i], out);
     dec.finish(out);
     if (dec.bad) throw std::runtime_error("Incorrect file format");
     return dec.ulen;

@@ -403,27 +403,43 @@ struct CoderLane {
 // (getSymbolFromProbability :727-763) touches LDS in two round trips of one
 // 16-byte read each instead of walking eight levels.  Depths 0 and 1 of the
 // left-count tree live in registers; depths 2..4 and 5..7 are stored as
-// 3-level subtrees, each one 16-byte RECORD of eight u16 (seven nodes and a
-// pad; exact order at decide3) so a single ds_read_b128 fetches everything the next three decisions can
+// 3-level subtrees, each one 16-byte RECORD of eight u16 (seven nodes and one
+// spare slot; exact order at decide3) so a single ds_read_b128 fetches everything the next three decisions can
 // need, and those decisions are then taken in registers.  (Measured with
 // tools/lds_probe.hip: at these occupancies a u16 LDS read costs the CU about
-// as much as a 16-byte one, and the seven separate u16 reads per subtree were
-// what bounded the previous form of this kernel.)  Same left-count tree as
-// the encoder's, same counts, same sums, same symbols.
+// as much as a 16-byte one.)  Same left-count tree as the encoder's, same
+// counts, same sums, same symbols.
 //   records  0..3   : subtrees rooted at the depth-2 nodes (index = complemented top 2 symbol bits)
-//   records  4..35  : subtrees rooted at the depth-5 nodes (index = complemented top 5 symbol bits)
+//   records  4..35  : subtrees rooted at the depth-5 nodes (index = complemented top 5 symbol bits);
+//                     their spare slot holds S = the count of all eight symbols under the record
 // kRecShift = log2(bytes between consecutive records of one lane): 10 on the
 // GPU (64 lanes x 16 B, lane-minor: any 16 lanes of a ds_read_b128 group cover
 // all 64 banks whatever records they address), 4 on the host.
+//
+// THE WALK WORKS ON A SCALED REMAINDER.  The reference forms
+//     unscaled = (((code - lower) + 1) * total - 1) / range          (getUnscaledCode :703-716)
+// and looks for the symbol s with cum(s) <= unscaled < cum(s+1).  With
+// R0 = (code - lower + 1) * total - 1 that is  cum(s)*range <= R0 < cum(s+1)*range
+// (all integers), so the quotient is never needed: keep R = R0 - below*range,
+// where `below` counts the symbols left of the current subtree; at a node whose
+// left subtree holds `a` symbols the walk goes left iff R < a*range, and going
+// right subtracts a*range.  One decision = one 24-bit multiply, one
+// subtract-with-borrow (the borrow IS "went left") and one unsigned minimum
+// (R < a*range leaves R, otherwise R - a*range is the smaller of the two) --
+// no lane-mask select on the critical chain.  At the leaf R0 - R = cumLo*range
+// is the very numerator applySymbolRange (:256-299) divides by total, and
+// cnt*range for the upper bound comes from S and the three products of the low
+// record: width(left child) = a, width(right child) = width(parent) - a.
 // ===========================================================================
 template <uint32_t kRecShift>
 struct SubtreeModel {
     // What three decisions inside one record leave to be written back: the whole record with the
-    // three nodes on the path incremented where the walk went left -- ONE 16-byte store.  (Three
-    // u16 stores of just the changed nodes need fewer vector instructions but two more LDS
-    // instructions per record, and an LDS instruction is the dearer of the two here.)
+    // three nodes on the path incremented where the walk went left (and S + 1 in a low record) --
+    // ONE 16-byte store.  (Three u16 stores of just the changed nodes need fewer vector
+    // instructions but two more LDS instructions per record, and an LDS instruction is the dearer
+    // of the two here.)
     struct Path {
-        uint8_t *rec;
+        uint32_t rec;                   // byte offset of the record from `col`
         uint32_t w0, w1, w2, w3;
     };
 
@@ -432,119 +448,108 @@ struct SubtreeModel {
     Path owed;                          // write-back of the previous symbol's low record, not yet issued
 
     static constexpr uint32_t kRecords = kDecodeRecords;
+    static constexpr uint32_t kLowBase = 4u << kRecShift;      // byte offset of low record 0
 
     GPUAR_LANE void reset() {
         root = 128u;
         half0 = half1 = 64u;
         // nothing owed yet: a write-back that rewrites record 35 with its initial values
-        owed.rec = col + ((kRecords - 1u) << kRecShift);
+        owed.rec = (kRecords - 1u) << kRecShift;
         owed.w0 = 4u | (2u << 16);
-        owed.w1 = 2u << 16;
+        owed.w1 = 8u | (2u << 16);
         owed.w2 = owed.w3 = 1u | (1u << 16);
 #pragma unroll 1
         for (uint32_t r = 0; r < kRecords; ++r) {
             const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
-            const uint32_t ab = top | ((top >> 1) << 16);          // a, b0
-            const uint32_t xb = (top >> 1) << 16;                  // -, b1
-            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // c0, c1 ; c2, c3
+            const uint32_t ab = top | ((top >> 1) << 16);          // a, bR
+            const uint32_t xb = (r < 4u ? 0u : 8u) | ((top >> 1) << 16);   // S (low records) / unused, bL
+            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // cRR, cRL ; cLR, cLL
             store128(col + (r << kRecShift), ab, xb, cc, cc);
         }
     }
 
-    // Three decisions inside the record whose 16 bytes are `q`.  State: `below`
-    // = count of symbols left of the current node's range, `upper` = count of
-    // symbols left of its right end, `npath` = the COMPLEMENTED symbol bits
-    // decided so far, MSB first.  Every decision is kept as "went LEFT": that is
-    // what the node update adds, and npath = 2 * npath + left is one
-    // add-with-carry of the same compare; records and the nodes inside them are
-    // simply stored in complemented order so that npath indexes them directly.
-    // The decoder never forms the quotient unscaled = floor(num / range) of
-    // getUnscaledCode (:703-716): for an integer s, unscaled < s  <=>  num <
-    // s * range  <=>  num + 1 <= s * range, so each decision is one 24-bit
-    // multiply and a compare -- exact, and no division by the lane-varying
-    // range.  Record layout (the two candidates of a decision sit in the same
-    // half of two dwords and one select picks both grandchildren at once; L/R =
-    // left/right child):
-    //     w0 = a | bR << 16     w1 = - | bL << 16     w2 = cRR | cRL << 16     w3 = cLR | cLL << 16
-    GPUAR_LANE Path decide3(uint8_t *rec, const Quad &q, uint32_t num1, uint32_t range, uint32_t &below, uint32_t &upper, uint32_t &npath) {
+    // one decision on the scaled remainder: went left iff R < prod; going right takes prod off R
+    static GPUAR_LANE bool decide(uint32_t &R, uint32_t prod) {
+        const uint32_t d = R - prod;
+        const bool left = R < prod;
+        R = d < R ? d : R;                                 // == left ? R : d  (prod >= 1)
+        return left;
+    }
+
+    // Three decisions inside the record whose 16 bytes are `q`.  `npath` = the
+    // COMPLEMENTED symbol bits decided so far, MSB first: every decision is kept
+    // as "went LEFT" -- that is what the borrow of the subtraction says, what the
+    // node update adds, and npath = 2 * npath + left is one add-with-carry of it;
+    // records and the nodes inside them are simply stored in complemented order
+    // so that npath indexes them directly.  Record layout (the two candidates of
+    // a decision sit in the same half of two dwords, so one select picks both
+    // grandchildren at once; L/R = left/right child):
+    //     w0 = a | bR << 16     w1 = S | bL << 16     w2 = cRR | cRL << 16     w3 = cLR | cLL << 16
+    // kLow: the record is a low one -- also returns W = cnt(symbol) * range through `width`.
+    template <bool kLow>
+    GPUAR_LANE Path decide3(uint32_t rec, const Quad &q, uint32_t range, uint32_t &R, uint32_t &npath, uint32_t &width) {
         const uint32_t *w = q.w;
-        const uint32_t a = w[0] & 0xFFFFu;
-        const uint32_t sa = below + a;
-        const bool la = num1 <= GPUAR_MUL24_VV(sa, range);
-        below = la ? below : sa;
-        upper = la ? sa : upper;
-        npath = GPUAR_ADDC(npath, npath, la);
+        const uint32_t pa = GPUAR_MUL24_VV(w[0] & 0xFFFFu, range);
+        const bool la = decide(R, pa);
         const uint32_t bw = la ? w[1] : w[0];                 // the chosen child sits in its high half
-        const uint32_t b = bw >> 16;
         const uint32_t cc = la ? w[3] : w[2];                 // both grandchildren under the chosen child
-        const uint32_t sb = below + b;
-        const bool lb = num1 <= GPUAR_MUL24_VV(sb, range);
-        // both candidates of the third decision, formed while the compare above settles
-        // (left: below stays; right: below becomes sb)
-        const uint32_t sc_left = GPUAR_ADD_HI16(below, cc);
-        const uint32_t sc_right = GPUAR_ADD_LO16(sb, cc);
-        below = lb ? below : sb;
-        upper = lb ? sb : upper;
-        npath = GPUAR_ADDC(npath, npath, lb);
-        const uint32_t sc = lb ? sc_left : sc_right;
-        const bool lc = num1 <= GPUAR_MUL24_VV(sc, range);
-        below = lc ? below : sc;
-        upper = lc ? sc : upper;
-        npath = GPUAR_ADDC(npath, npath, lc);
+        const uint32_t pb = GPUAR_MUL24_VV(bw >> 16, range);
+        const bool lb = decide(R, pb);
+        const uint32_t pc = GPUAR_MUL24_VV(lb ? cc >> 16 : cc & 0xFFFFu, range);
+        const bool lc = decide(R, pc);
+        npath = 8u * npath + (la ? 4u : 0u) + (lb ? 2u : 0u) + (lc ? 1u : 0u);
+        if (kLow) {
+            const uint32_t ps = GPUAR_MUL24_VV(w[1] & 0xFFFFu, range);
+            const uint32_t gw = la ? pa : ps - pa;             // width of the chosen child, scaled
+            const uint32_t pw = lb ? pb : gw - pb;
+            width = lc ? pc : pw - pc;
+        }
         // the record with +1 on the path nodes where the walk went left: the child's dword and the
         // grandchildren's dword are bumped in their selected copies and put back by the same selects
         const uint32_t bw_new = bw + (lb ? 0x10000u : 0u);
         const uint32_t cc_new = cc + (lc ? (lb ? 0x10000u : 1u) : 0u);
         Path p;
         p.rec = rec;
-        p.w0 = GPUAR_ADDC(la ? w[0] : bw_new, 0u, la);        // a sits in the low half of w0
-        p.w1 = la ? bw_new : w[1];
+        p.w0 = (la ? w[0] : bw_new) + (la ? 1u : 0u);         // a sits in the low half of w0
+        p.w1 = (la ? bw_new : w[1]) + (kLow ? 1u : 0u);       // S counts every symbol that lands here
         p.w2 = la ? w[2] : cc_new;
         p.w3 = la ? cc_new : w[3];
         return p;
     }
-    GPUAR_LANE void write_back(const Path &p) { store128(p.rec, p.w0, p.w1, p.w2, p.w3); }
+    GPUAR_LANE void write_back(const Path &p) { store128(col + p.rec, p.w0, p.w1, p.w2, p.w3); }
 
-    // The symbol s with cum(s) <= floor((num1 - 1) / range) < cum(s+1); cum_lo = cum(s),
-    // cum_hi = cum(s+1).  Memory-safe for any num1 (a value beyond the model's
-    // total simply walks right).
+    // The symbol s with cum(s)*range <= R0 < cum(s+1)*range.  On return R = R0 - cum(s)*range
+    // and width = cnt(s)*range.  Memory-safe for any R0 (a value beyond the model's total simply
+    // walks right).
     // Order of LDS traffic (LDS operations of a wavefront complete in order):
-    //   read mid record -> write back the PREVIOUS symbol's low record (mid and
-    //   low records are disjoint; a later read of the same low record comes
-    //   after this write) -> read low record -> write back the mid record ->
+    //   write back the PREVIOUS symbol's low record -> read mid record -> read low record (a later
+    //   read of the same low record comes after that write) -> write back the mid record ->
     //   (low record's write-back is owed to the next call / flush()).
-    // Each write-back thus sits in the shadow of a read instead of in front of it.
     // `in_shadow()` is called right after the first record read has been issued:
     // work that the symbol search does not depend on goes there.
     template <typename Shadow>
-    GPUAR_LANE uint32_t decode_step(uint32_t num1, uint32_t range, uint32_t total, uint32_t &cum_lo, uint32_t &cum_hi,
-                                    Shadow &&in_shadow) {
-        const bool l0 = num1 <= GPUAR_MUL24_VV(root, range);
-        uint32_t below = l0 ? 0u : root;
-        uint32_t upper = l0 ? root : total;
+    GPUAR_LANE uint32_t decode_step(uint32_t R0, uint32_t range, uint32_t &R, uint32_t &width, Shadow &&in_shadow) {
+        R = R0;
+        const bool l0 = decide(R, GPUAR_MUL24_VV(root, range));
         const uint32_t h = l0 ? half0 : half1;
-        const uint32_t s1 = below + h;
-        const bool l1 = num1 <= GPUAR_MUL24_VV(s1, range);
-        below = l1 ? below : s1;
-        upper = l1 ? s1 : upper;
-        uint32_t npath = GPUAR_ADDC(l0 ? 2u : 0u, 0u, l1);    // complemented top two symbol bits
-        uint8_t *rec_mid = col + (npath << kRecShift);
-        Quad q_mid = load128(rec_mid);                        // ds_read_b128 #1 ...
+        const bool l1 = decide(R, GPUAR_MUL24_VV(h, range));
+        uint32_t npath = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented top two symbol bits
+        write_back(owed);
+        const uint32_t rec_mid = npath << kRecShift;
+        Quad q_mid = load128(col + rec_mid);                  // ds_read_b128 #1
         GPUAR_PIN_LOAD(q_mid);
-        write_back(owed);                                     // ... with the previous symbol's write-back behind it
-        in_shadow();
-        root += l0 ? 1u : 0u;                                 // register nodes: also in the shadow of read #1
+        root += l0 ? 1u : 0u;                                 // register nodes: in the shadow of read #1
         const uint32_t h_new = h + (l1 ? 1u : 0u);            // the depth-1 node on the path
         half0 = l0 ? h_new : half0;
         half1 = l0 ? half1 : h_new;
-        const Path p_mid = decide3(rec_mid, q_mid, num1, range, below, upper, npath);
-        uint8_t *rec_low = col + ((4u + npath) << kRecShift); // npath = complemented top five symbol bits
-        Quad q_low = load128(rec_low);                        // ds_read_b128 #2 ...
+        in_shadow();
+        uint32_t unused = 0;
+        const Path p_mid = decide3<false>(rec_mid, q_mid, range, R, npath, unused);
+        const uint32_t rec_low = kLowBase + (npath << kRecShift);   // npath = complemented top five symbol bits
+        Quad q_low = load128(col + rec_low);                  // ds_read_b128 #2 ...
         GPUAR_PIN_LOAD(q_low);
-        write_back(p_mid);                                    // ... with the first write-back behind it
-        owed = decide3(rec_low, q_low, num1, range, below, upper, npath);
-        cum_lo = below;
-        cum_hi = upper;
+        write_back(p_mid);                                    // ... with the mid record's write-back behind it
+        owed = decide3<true>(rec_low, q_low, range, R, npath, width);
         return npath ^ 255u;
     }
 
@@ -552,18 +557,40 @@ struct SubtreeModel {
     GPUAR_LANE void flush() { write_back(owed); }
 };
 
-// Decoder state of one packet: SubtreeModel, the interval as the encoder keeps
-// it (lo | (0xFFFF - hi) << 16, so both bounds renormalise with plain left
-// shifts), the code value as its OFFSET above lo, and a bit reader.
+// Per-symbol constants of the decoder, wave-uniform, one 16-byte scalar load: the reciprocal of
+// the model total (Recip above), the total itself and total - 1.
+struct DecodeConst {
+    uint32_t mul, shift, total, total_m1;
+};
+struct DecodeConstTable {
+    DecodeConst c[kPacket];
+    constexpr DecodeConstTable() : c{} {
+        const RecipTable r = RecipTable();
+        for (uint32_t i = 0; i < kPacket; ++i) {
+            c[i].mul = r.r[i].mul;
+            c[i].shift = r.r[i].shift;
+            c[i].total = 256u + i;
+            c[i].total_m1 = 255u + i;
+        }
+    }
+};
+
+// Decoder state of one packet: SubtreeModel, the interval as its lower bound
+// and its WIDTH (lo, range = hi - lo + 1), the code value as its OFFSET above
+// lo, and a bit reader.
 //
 // Why the offset: every renormalisation step of readEncodedBits (:787-836)
 // subtracts the same constant (0, 0x8000 or 0x4000) from lo, hi and code and
 // then doubles them, pulling one stream bit into code.  code - lo therefore
-// just doubles and takes the bit: after n = e + u steps
-//     off' = (off << n) | next n stream bits,
+// just doubles and takes the bit, and hi - lo + 1 just doubles: after
+// n = e + u steps
+//     off' = (off << n) | next n stream bits,        range' = width << n,
 // one 64-bit shift of off:window, with none of the masks and the conditional
 // complement the absolute code value needs; getUnscaledCode's numerator
 // ((code - lower) + 1) * total - 1 (:703-716) is off * total + (total - 1).
+// Only e and u themselves are read off the bit patterns of the new bounds
+// a = lo' and h = hi' (closed form above bswap32): e = agreeing MSBs of a and h,
+// u = the run below them where a has 1 and h has 0, and lo'' = (a << n) & 0x7FFF.
 //
 // Bit reader: two aligned big-endian dwords (w0:w1) hold the stream at the
 // current position, `rem` (0..31) bits of w0 are still unread, a third dword
@@ -580,7 +607,8 @@ struct DecoderLane {
     const uint8_t *base;       // start of the bytes this wavefront reads (the same in every lane: a scalar on the GPU)
     uint32_t next;             // offset from base of the dword after `ahead` (base + next is 4-byte aligned)
     uint32_t last;             // offset of the last dword that still holds a readable byte
-    uint32_t p;                // lo | (0xFFFF - hi) << 16
+    uint32_t lo;               // lower bound of the interval (< 2^15 between symbols)
+    uint32_t range;            // hi - lo + 1  (2^14 < range <= 2^16 between symbols)
     uint32_t off;              // code - lo
     uint32_t ulen;
     uint32_t outword;
@@ -607,7 +635,11 @@ struct DecoderLane {
             // consume the OLD prefetched dword before the new load is issued:
             // otherwise the wait for the old one (vmcnt) also waits for the new one
             GPUAR_PIN_ORDER(w1);
+#if defined(GPUAR_EXP_NOFETCH)
+            next += 4;
+#else
             ahead = fetch();
+#endif
         }
     }
 
@@ -643,7 +675,8 @@ struct DecoderLane {
         // the first 16 bits of the body are the initial code value (initializeDecoder :582-603)
         const uint32_t used = 8u * misalign + 16u;            // 16, 24, 32 or 40 bits of w0:w1 are behind us
         const uint64_t both = (static_cast<uint64_t>(w0) << 32) | w1;
-        p = 0;                                                // lo = 0, hi = 0xFFFF
+        lo = 0;                                               // lo = 0, hi = 0xFFFF
+        range = 0x10000u;
         off = static_cast<uint32_t>(both >> (64u - used)) & 0xFFFFu;
         rem = (32u - used) & 31u;                             // used == 32: w0 is spent, the window starts at w1
         if (used > 32u) {
@@ -654,43 +687,47 @@ struct DecoderLane {
         owed_bits = 0;
     }
 
+    // applySymbolRange (:256-299) and the renormalisation (:787-836) on (lo, range, off), given the
+    // two numerators cumLo*range and cumHi*range.  Shared by the plain and the hand-scheduled step.
+    GPUAR_LANE void narrow(uint32_t num_lo, uint32_t num_hi, const DecodeConst &k) {
+        const Recip rc = {k.mul, k.shift};
+        const uint32_t dn = div_total(num_lo, rc);
+        const uint32_t up = div_total(num_hi, rc);
+        const uint32_t a = lo + dn;                           // new lo
+        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+        const uint32_t h = a + wd - 1u;                       // new hi
+        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
+        const uint32_t e = GPUAR_CLZ32((((a ^ h) & 0xFFFFu) << 16) | 0xFFFFu);
+        // leading ones of (a & ~h) below the e agreeing bits and the first differing one, counted
+        // as the leading zeros of its complement shifted up with ones behind it
+        const uint32_t u = GPUAR_CLZ32(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        const uint32_t n = e + u;                             // <= 31 fresh bits
+        lo = (a << n) & 0x7FFFu;
+        range = wd << n;
+        off = static_cast<uint32_t>((((static_cast<uint64_t>(off - dn) << 32) | peek()) << n) >> 32);
+        owed_bits = n;
+    }
+
     // decodes symbol i and returns it; the caller places it (see put_symbol / flush)
-    GPUAR_LANE uint32_t step_symbol(uint32_t i, Recip rc) {
-        uint32_t total = 256u + i;                            // i is the same in every lane
-        GPUAR_UNIFORM(total);
-        const uint32_t lo = p & 0xFFFFu;
-        const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
-        const uint32_t range = above - (p >> 16);             // hi - lo + 1
-        const uint32_t num1 = GPUAR_MUL24(off, total) + total;   // getUnscaledCode's numerator (:703-716), plus one
-        // No symbol owns a code value with floor(num / range) >= total, i.e. off >= range (:873-877,
+    GPUAR_LANE uint32_t step_symbol(const DecodeConst &k) {
+        const uint32_t R0 = GPUAR_MUL24(off, k.total) + k.total_m1;   // getUnscaledCode's numerator (:703-716)
+        // No symbol owns a code value with floor(R0 / range) >= total, i.e. off >= range (:873-877,
         // where the reference stops decoding the packet).  Such a packet is
         // malformed: flag it and keep going -- the walk stays inside the tree and
         // the output inside its 8192 bytes whatever the bits are.
         bad = bad || off >= range;
-        uint32_t cum_lo, cum_hi;
-        const uint32_t sym = model.decode_step(num1, range, total, cum_lo, cum_hi, [this]() {
+        uint32_t R, width;
+        const uint32_t sym = model.decode_step(R0, range, R, width, [this]() {
             skip(owed_bits);          // the stream window is next needed at the end of this symbol
         });
-        // applySymbolRange :256-299 on (lo, nh), as CoderLane::step does
-        const uint32_t up = div_total(GPUAR_MUL24_VV(cum_hi, range), rc);
-        const uint32_t dn = div_total(GPUAR_MUL24_VV(cum_lo, range), rc);
-        const uint32_t a = lo + dn;                           // new lo
-        const uint32_t b = above - up;                        // 0xFFFF - new hi
-        const uint32_t off_n = off - dn;
-        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
-        const uint32_t e = GPUAR_CLZ32(~((a ^ b) << 16));
-        const uint32_t a1 = (a << e) & 0xFFFFu, b1 = (b << e) & 0xFFFFu;
-        const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
-        p = GPUAR_PK_SHL16(a1 | (b1 << 16), u) & 0x7FFF7FFFu;
-        const uint32_t n = e + u;                             // <= 31 fresh bits
-        off = static_cast<uint32_t>((((static_cast<uint64_t>(off_n) << 32) | peek()) << n) >> 32);
-        owed_bits = n;
+        const uint32_t num_lo = R0 - R;                       // cumLo * range
+        narrow(num_lo, num_lo + width, k);
         return sym;
     }
 
     // simple placement: one dword store per four symbols
-    GPUAR_LANE void step(uint32_t i, Recip rc, uint8_t *out) {
-        const uint32_t sym = step_symbol(i, rc);
+    GPUAR_LANE void step(uint32_t i, const DecodeConst &k, uint8_t *out) {
+        const uint32_t sym = step_symbol(k);
         outword |= sym << (8u * (i & 3u));
         if ((i & 3u) == 3u) {
             store32(out + (i & ~3u), outword);

@@ -12,6 +12,7 @@
 using namespace gpuar;
 
 static const RecipTable kRecip = RecipTable();
+static const DecodeConstTable kDecode = DecodeConstTable();
 
 extern "C" {
 
@@ -57,7 +58,7 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
         const uint64_t readable = static_cast<uint64_t>(limit - (stream + pkt_offsets[p]));
         dec.open(reinterpret_cast<uint8_t *>(records.data()), stream + pkt_offsets[p], 0,
                  readable < 0x7FFFFFFFu ? static_cast<uint32_t>(readable) : 0x7FFFFFFFu, true);
-        for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kRecip.r[i], o);
+        for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kDecode.c[i], o);
         dec.finish(o);
         bad += dec.bad ? 1 : 0;
     }
