@@ -326,31 +326,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // DecoderLane::step_symbol instruction for instruction (same integers), which the CPU tests pin
 // against the oracle; the GPU parity tests then compare this path with the oracle directly.
 // ---------------------------------------------------------------------------
-#if defined(GPUAR_EXP_NOWAIT)
-#define GPUAR_EXP_WAIT1 ""
-#define GPUAR_EXP_WAIT2 ""
-#elif defined(GPUAR_EXP_NOWAIT1)
-#define GPUAR_EXP_WAIT1 ""
-#define GPUAR_EXP_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
-#elif defined(GPUAR_EXP_NOWAIT2)
-#define GPUAR_EXP_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
-#define GPUAR_EXP_WAIT2 ""
-#else
-#define GPUAR_EXP_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
-#define GPUAR_EXP_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
-#endif
-#define GPUAR_DUMMY4 "v_add_u32 %[t0], 1, %[t0]\n\tv_add_u32 %[t1], 1, %[t1]\n\tv_add_u32 %[t0], 1, %[t0]\n\tv_add_u32 %[t1], 1, %[t1]\n\t"
-#define GPUAR_DUMMY16 GPUAR_DUMMY4 GPUAR_DUMMY4 GPUAR_DUMMY4 GPUAR_DUMMY4
-#if defined(GPUAR_EXP_ADD_A)
-#define GPUAR_EXP_PAD_A GPUAR_DUMMY16
-#else
-#define GPUAR_EXP_PAD_A ""
-#endif
-#if defined(GPUAR_EXP_ADD_B)
-#define GPUAR_EXP_PAD_B GPUAR_DUMMY16
-#else
-#define GPUAR_EXP_PAD_B ""
-#endif
 #define GPUAR_SDWA_W0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
 #define GPUAR_SDWA_W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
 #define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
@@ -391,7 +366,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e; \
         unsigned long long ma, mc, mj; \
         asm volatile( \
-            GPUAR_EXP_PAD_A GPUAR_EXP_WAIT1 /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
+            "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: w0 = a | bR << 16, w1 = - | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
             "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
@@ -424,7 +399,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 v211, v203, %[cc], %[ma]\n\t" \
             "v_addc_co_u32 v208, %[mj], v208, 0, %[ma]\n\t" \
             "ds_write_b128 %[am], v[208:211]\n\t" \
-            GPUAR_EXP_WAIT2 GPUAR_EXP_PAD_B \
+            "s_waitcnt lgkmcnt(1)\n\t" \
          /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
             "v_mul_u32_u24_sdwa %[pa], v212, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[pa]\n\t" \

@@ -635,11 +635,7 @@ struct DecoderLane {
             // consume the OLD prefetched dword before the new load is issued:
             // otherwise the wait for the old one (vmcnt) also waits for the new one
             GPUAR_PIN_ORDER(w1);
-#if defined(GPUAR_EXP_NOFETCH)
-            next += 4;
-#else
             ahead = fetch();
-#endif
         }
     }
 
