@@ -330,12 +330,15 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_SDWA_W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
 #define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
 
-// One symbol of the hand-scheduled decoder (see above).  Uses decode_wave's locals by name.
-#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_MUL, K_SHIFT, NP_OUT)                                                             \
-    {                                                                                                               \
-        uint32_t R0, R, np, am, t0, t1, t2; \
-        unsigned long long m0, m1; \
-        asm volatile( \
+// One symbol of the hand-scheduled decoder (see above), in text pieces.  Two variants are assembled from them:
+//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the low record of a
+//            symbol is rebuilt by the NEXT symbol's statement A, in the shadow of its LDS read, from the record as
+//            read (v212-v215) and the path (lane masks lma, lmc and lincb / lx) -- lane masks can only be carried
+//            from one statement to the next in scalar registers where the compiler sees uniform control flow;
+//   PLAIN    for the one wavefront of a file that holds its short last packet (lanes drop out under `if`):
+//            statement BC rebuilds the record itself into v204-v207.
+// They use decode_wave's locals by name.
+#define GPUAR_A_HEAD \
             "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
             "v_add_u32 %[R0], -1, %[R0]\n\t" /* off*total + total - 1 */ \
@@ -348,24 +351,30 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 %[np], 0, 2, %[m0]\n\t" \
             "v_addc_co_u32 %[np], vcc, %[np], 0, %[m1]\n\t" /* complemented top two symbol bits */ \
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
-            "ds_read_b128 v[200:203], %[am]\n\t" /* READ #1: mid record ... */ \
-            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* ... and the previous symbol's low record behind it */ \
+            "ds_read_b128 v[200:203], %[am]\n\t" /* READ #1: mid record */ \
+
+#define GPUAR_A_SHADOW_CARRIED \
+         /* in its shadow: the PREVIOUS symbol's low record (v212-v215 as read, its path in lma / lincb / lx / lmc) is rebuilt and written back */ \
+            "v_add_u32 %[lbw], %[lbw], %[lincb]\n\t" \
+            "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t" \
+            "v_add_u32 %[lcc], %[lcc], %[lx]\n\t" \
+            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t" \
+            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t" \
+            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t" \
+            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t" \
+            "v_addc_co_u32 v204, vcc, v204, 0, %[lma]\n\t" \
+            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */ \
+            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" \
+
+#define GPUAR_A_SHADOW_PLAIN \
+            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* the previous symbol's low record, rebuilt by its statement BC */
+#define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
             "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
             "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
-            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
-              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
-              "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
-            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
-              "v"(o0), "v"(o1), "v"(o2), "v"(o3) \
-            : "vcc", "memory"); \
-         /* shadow of read #1: the stream reader catches up with the previous symbol */ \
-        dec.skip(dec.owed_bits); \
-        const uint32_t window = dec.peek(); \
-        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e; \
-        unsigned long long ma, mc, mj; \
-        asm volatile( \
+
+#define GPUAR_BC_TEXT \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: w0 = a | bR << 16, w1 = - | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
             "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
@@ -402,27 +411,27 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "s_waitcnt lgkmcnt(1)\n\t" \
          /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
             "v_mul_u32_u24_sdwa %[pa], v212, %[rng]" GPUAR_SDWA_W0 \
-            "v_sub_co_u32 %[t1], %[ma], %[R], %[pa]\n\t" \
+            "v_sub_co_u32 %[t1], %[lma], %[R], %[pa]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_mul_u32_u24_sdwa %[ps], v213, %[rng]" GPUAR_SDWA_W0 \
-            "v_cndmask_b32 %[bw], v212, v213, %[ma]\n\t" \
-            "v_cndmask_b32 %[cc], v214, v215, %[ma]\n\t" \
-            "v_mul_u32_u24_sdwa %[pb], %[bw], %[rng]" GPUAR_SDWA_W1 \
+            "v_cndmask_b32 %[lbw], v212, v213, %[lma]\n\t" \
+            "v_cndmask_b32 %[lcc], v214, v215, %[lma]\n\t" \
+            "v_mul_u32_u24_sdwa %[pb], %[lbw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_sub_u32 %[t3], %[ps], %[pa]\n\t" \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
-            "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
+            "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
-            "v_sub_co_u32 %[t1], %[mc], %[R], %[pc]\n\t" \
+            "v_sub_co_u32 %[t1], %[lmc], %[R], %[pc]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[pa], %[ma]\n\t" /* width of the depth-6 subtree on the path, scaled */ \
+            "v_cndmask_b32 %[t3], %[t3], %[pa], %[lma]\n\t" /* width of the depth-6 subtree on the path, scaled */ \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
             "v_sub_u32 %[t3], %[t3], %[pb]\n\t" \
             "v_cndmask_b32 %[t3], %[t3], %[pb], vcc\n\t" /* ... of the depth-7 pair */ \
             "v_sub_u32 %[t3], %[t3], %[pc]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[pc], %[mc]\n\t" /* W = cnt(symbol) * range */ \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" /* all eight complemented symbol bits */ \
+            "v_cndmask_b32 %[t3], %[t3], %[pc], %[lmc]\n\t" /* W = cnt(symbol) * range */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_add_u32 %[t1], %[t0], %[t3]\n\t" /* cumHi * range */ \
@@ -443,29 +452,86 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_lshlrev_b32 %[a], %[n], %[a]\n\t" \
             "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
-         /* ---- low record rebuilt -> owed (written back by the next statement A) */ \
+
+#define GPUAR_BC_TAIL_CARRIED \
+         /* ---- what the next statement A needs to rebuild this low record (it does so in the shadow of its read) */ \
+            "v_cndmask_b32 %[lincb], 0, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
+
+#define GPUAR_BC_TAIL_PLAIN \
+         /* ---- low record rebuilt -> v204-v207 (written back by the next statement A) */ \
             "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" \
-            "v_add_u32 %[bw], %[bw], %[t3]\n\t" \
+            "v_add_u32 %[lbw], %[lbw], %[t3]\n\t" \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
-            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
-            "v_add_u32 %[cc], %[cc], %[t2]\n\t" \
-            "v_cndmask_b32 v204, %[bw], v212, %[ma]\n\t" \
-            "v_cndmask_b32 v205, v213, %[bw], %[ma]\n\t" \
-            "v_cndmask_b32 v206, %[cc], v214, %[ma]\n\t" \
-            "v_cndmask_b32 v207, v215, %[cc], %[ma]\n\t" \
-            "v_addc_co_u32 v204, %[mj], v204, 0, %[ma]\n\t" \
-            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */ \
+            "v_cndmask_b32 %[t2], 0, %[t2], %[lmc]\n\t" \
+            "v_add_u32 %[lcc], %[lcc], %[t2]\n\t" \
+            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t" \
+            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t" \
+            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t" \
+            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t" \
+            "v_addc_co_u32 v204, %[mj], v204, 0, %[lma]\n\t" \
+            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */
+
+#define GPUAR_STEP_TAIL(NP_OUT) \
+        dec.off = static_cast<uint32_t>((((static_cast<uint64_t>(dec.off - dn) << 32) | window) << n) >> 32); \
+        dec.owed_bits = n; \
+        NP_OUT = np;
+
+#define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
+    { \
+        uint32_t R0, R, np, am, t0, t1, t2; \
+        unsigned long long m0, m1; \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL \
+            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
+              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
+            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
+              [lincb] "v"(lincb), [lma] "s"(lma), [lmc] "s"(lmc), "v"(r0), "v"(r1), "v"(r2), "v"(r3) \
+            : "vcc", "memory", "v204", "v205", "v206", "v207"); \
+        /* shadow of read #1: the stream reader catches up with the previous symbol */ \
+        dec.skip(dec.owed_bits); \
+        const uint32_t window = dec.peek(); \
+        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e; \
+        unsigned long long ma, mc, mj; \
+        asm volatile(GPUAR_BC_TEXT GPUAR_BC_TAIL_CARRIED \
             : [R] "+v"(R), [np] "+v"(np), [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [kff] "+v"(kff), [bad] "+v"(bad_min), \
               [oaddr] "=&v"(oaddr), [dn] "=&v"(dn), [n] "=&v"(n), [bw] "=&v"(bw), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), \
               [t2] "=&v"(t2), [t3] "=&v"(t3), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), [a] "=&v"(a), \
               [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), \
+              [lbw] "=&v"(lbw), [lcc] "=&v"(lcc), [lincb] "=&v"(lincb), [lx] "=&v"(lx), [lma] "=&s"(lma), [lmc] "=&s"(lmc), \
+              "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
+            : [R0] "v"(R0), [off] "v"(dec.off), [col] "v"(col_lds), [am] "v"(am), [k64k] "v"(k64k), \
+              [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)) \
+            : "vcc", "memory", "v208", "v209", "v210", "v211"); \
+        GPUAR_STEP_TAIL(NP_OUT) \
+    }
+
+#define GPUAR_DECODE_SYMBOL_PLAIN(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
+    { \
+        uint32_t R0, R, np, am, t0, t1, t2; \
+        unsigned long long m0, m1; \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL \
+            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
+              "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
+            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
+              "v"(o0), "v"(o1), "v"(o2), "v"(o3) \
+            : "vcc", "memory"); \
+        dec.skip(dec.owed_bits); \
+        const uint32_t window = dec.peek(); \
+        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e, lbw_, lcc_; \
+        unsigned long long ma, mc, mj, lma_, lmc_; \
+        asm volatile(GPUAR_BC_TEXT GPUAR_BC_TAIL_PLAIN \
+            : [R] "+v"(R), [np] "+v"(np), [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [kff] "+v"(kff), [bad] "+v"(bad_min), \
+              [oaddr] "=&v"(oaddr), [dn] "=&v"(dn), [n] "=&v"(n), [bw] "=&v"(bw), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), \
+              [t2] "=&v"(t2), [t3] "=&v"(t3), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), [a] "=&v"(a), \
+              [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), \
+              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
               "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
             : [R0] "v"(R0), [off] "v"(dec.off), [col] "v"(col_lds), [am] "v"(am), [k64k] "v"(k64k), \
               [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)) \
             : "vcc", "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"); \
-        dec.off = static_cast<uint32_t>((((static_cast<uint64_t>(dec.off - dn) << 32) | window) << n) >> 32); \
-        dec.owed_bits = n; \
-        NP_OUT = np;                                                                                                \
+        GPUAR_STEP_TAIL(NP_OUT) \
     }
 
 // `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit
@@ -489,11 +555,14 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     register uint32_t q1 asm("v201");
     register uint32_t q2 asm("v202");
     register uint32_t q3 asm("v203");
-    register uint32_t o0 asm("v204");          // low record of the previous symbol, rebuilt, not yet written back
+    register uint32_t o0 asm("v204");          // PLAIN: low record of the previous symbol, rebuilt, not yet written back
     register uint32_t o1 asm("v205");
     register uint32_t o2 asm("v206");
     register uint32_t o3 asm("v207");
-    o0 = dec.model.owed.w0, o1 = dec.model.owed.w1, o2 = dec.model.owed.w2, o3 = dec.model.owed.w3;
+    register uint32_t r0 asm("v212");          // CARRIED: low record of the previous symbol as read; statement A rebuilds it
+    register uint32_t r1 asm("v213");          // (path in lma / lincb / lx / lmc) and writes it back in the shadow of its read
+    register uint32_t r2 asm("v214");
+    register uint32_t r3 asm("v215");
     uint32_t oaddr = col_lds + dec.model.owed.rec - SubtreeModel<10>::kLowBase;      // the write carries offset:4096
     // min over the symbols of (off - range) mod 2^32: a value below 0xFFFF0000 means that some symbol met
     // off >= range, a code value no symbol owns (range <= 2^16, so off < range wraps to >= 0xFFFF0000)
@@ -501,46 +570,85 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u;
 
-    // The per-symbol constants come as ONE 64-byte scalar load per group of four symbols, issued a whole
-    // group ahead into the register set the group after next will read (two sets, taken in turn: no
-    // copies).  One load in flight at most matters: a scalar load counts in lgkmcnt like the LDS
-    // operations but may return out of order, so the waits of the symbol step are all of the form
-    // "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" -- satisfied as soon as the read
-    // is back whether or not the scalar load is.  (With lgkmcnt(0) waits, or with the model total needed
-    // from a load issued in the same group, every fourth symbol sat out a scalar-cache miss: 175 of 830
-    // cycles per symbol.)
-    typedef uint32_t ConstGroup __attribute__((ext_vector_type(16)));       // {mul, shift, total, total - 1} x 4
-    const ConstGroup *const_groups = reinterpret_cast<const ConstGroup *>(g_decode.c);
-    constexpr uint32_t kLastGroup = kPacket / 4u - 1u;
-    for (; i + 64u <= len_max; i += 64u) {
-        if (i + 64u <= dec.ulen) {                           // this lane decodes the whole block
-            uint32_t block[16];
-            ConstGroup ka = const_groups[i >> 2];
-#pragma unroll 1
-            for (uint32_t g = 0; g < 16u; g += 2u) {
-                const uint32_t group = (i >> 2) + g;         // wave-uniform
-                // the next group's constants are asked for AFTER the first symbol of this group: by then this
-                // group's own load (issued a group ago) has long landed, so the compiler's wait for it (a scalar
-                // load can only be waited for with lgkmcnt(0)) does not catch the new one in flight
-                uint32_t word, np_out;
-                GPUAR_DECODE_SYMBOL(ka[2], ka[0], ka[1], np_out) word = np_out;
-                const ConstGroup kb = const_groups[group + 1u];
-                GPUAR_DECODE_SYMBOL(ka[6], ka[4], ka[5], np_out) word |= np_out << 8;
-                GPUAR_DECODE_SYMBOL(ka[10], ka[8], ka[9], np_out) word |= np_out << 16;
-                GPUAR_DECODE_SYMBOL(ka[14], ka[12], ka[13], np_out) word |= np_out << 24;
-                block[g] = ~word;                            // np holds the COMPLEMENTED symbol bits
-                GPUAR_DECODE_SYMBOL(kb[2], kb[0], kb[1], np_out) word = np_out;
-                ka = const_groups[group + 2u <= kLastGroup ? group + 2u : kLastGroup];
-                GPUAR_DECODE_SYMBOL(kb[6], kb[4], kb[5], np_out) word |= np_out << 8;
-                GPUAR_DECODE_SYMBOL(kb[10], kb[8], kb[9], np_out) word |= np_out << 16;
-                GPUAR_DECODE_SYMBOL(kb[14], kb[12], kb[13], np_out) word |= np_out << 24;
-                block[g + 1u] = ~word;
-            }
-            uint4 *dst = reinterpret_cast<uint4 *>(out + i);
-#pragma unroll
-            for (uint32_t v = 0; v < 4; ++v) dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);
-        }
+    // The per-symbol reciprocals (Recip, 8 bytes per symbol) come as ONE 64-byte scalar load per EIGHT symbols,
+    // issued eight symbols before its first use into the register set the run after next will read (two
+    // sets, taken in turn: no copies); the model total is simply counted up.  Why so far ahead: a scalar load
+    // that misses its cache goes to L2 like everything else, and while the wavefronts stream their packets
+    // in and their output out, that round trip takes several symbol steps -- with the load issued one group
+    // of four symbols ahead every wavefront sat out ~170 of 790 cycles per symbol (measured by taking the
+    // vector loads and stores out: tools/kind_timing.py).  A scalar load counts in lgkmcnt like
+    // the LDS operations but may return out of order, so (a) the waits of the symbol step are all of the form
+    // "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" -- satisfied as soon as the read is
+    // back whether or not the scalar load is -- and (b) the next load is issued AFTER the first symbol of a run,
+    // i.e. behind the compiler's own lgkmcnt(0) for the run's constants, so that wait never catches it.
+    typedef uint32_t ConstRun __attribute__((ext_vector_type(16)));         // {mul, shift} x 8 symbols
+    const ConstRun *const_runs = reinterpret_cast<const ConstRun *>(g_recip.r);
+    constexpr uint32_t kLastRun = kPacket / 8u - 1u;
+#define GPUAR_DECODE_RUN(SYMBOL, K, TOTAL0, NEXT_LOAD, W0, W1)                                                       \
+    {                                                                                                                \
+        uint32_t word, np_out;                                                                                       \
+        SYMBOL((TOTAL0), K[0], K[1], np_out) word = np_out;                                                          \
+        NEXT_LOAD;                                                                                                   \
+        SYMBOL((TOTAL0) + 1u, K[2], K[3], np_out) word |= np_out << 8;                                               \
+        SYMBOL((TOTAL0) + 2u, K[4], K[5], np_out) word |= np_out << 16;                                              \
+        SYMBOL((TOTAL0) + 3u, K[6], K[7], np_out) word |= np_out << 24;                                              \
+        block[W0] = ~word; /* np holds the COMPLEMENTED symbol bits */                                               \
+        SYMBOL((TOTAL0) + 4u, K[8], K[9], np_out) word = np_out;                                                     \
+        SYMBOL((TOTAL0) + 5u, K[10], K[11], np_out) word |= np_out << 8;                                             \
+        SYMBOL((TOTAL0) + 6u, K[12], K[13], np_out) word |= np_out << 16;                                            \
+        SYMBOL((TOTAL0) + 7u, K[14], K[15], np_out) word |= np_out << 24;                                            \
+        block[W1] = ~word;                                                                                           \
     }
+#define GPUAR_DECODE_BLOCK(SYMBOL)                                                                                   \
+    {                                                                                                                \
+        uint32_t block[16];                                                                                          \
+        ConstRun ka = const_runs[i >> 3];                                                                            \
+        _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 4u) {                                                 \
+            const uint32_t run = (i >> 3) + (g >> 1); /* wave-uniform */                                             \
+            const uint32_t total0 = 256u + i + 4u * g;                                                               \
+            ConstRun kb;                                                                                             \
+            GPUAR_DECODE_RUN(SYMBOL, ka, total0, kb = const_runs[run + 1u], g, g + 1u)                              \
+            GPUAR_DECODE_RUN(SYMBOL, kb, total0 + 8u, ka = const_runs[run + 2u <= kLastRun ? run + 2u : kLastRun], g + 2u, g + 3u) \
+        }                                                                                                            \
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i);                                                             \
+        _Pragma("unroll") for (uint32_t v = 0; v < 4; ++v)                                                           \
+            dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);                 \
+    }
+
+    // ---- blocks that every lane of the wavefront owns: uniform control flow, CARRIED variant ----
+    const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
+    {
+        uint32_t lbw, lcc, lincb, lx;
+        unsigned long long lma, lmc;
+        // The write-back the plain step still owes, in carried form: with empty lane masks the rebuild
+        // yields (lbw + lincb, r1 + 1, lcc, r3).  (Initial values go through asm: a known constant would be
+        // spliced into the statements as an immediate.)
+        asm volatile("s_mov_b64 %0, 0\n\ts_mov_b64 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\tv_mov_b32 %4, 0\n\tv_mov_b32 %5, 0"
+                     : "=s"(lma), "=s"(lmc), "=v"(lincb), "=v"(lx), "=v"(r0), "=v"(r2));
+        lbw = dec.model.owed.w0, r1 = dec.model.owed.w1 - 1u, lcc = dec.model.owed.w2, r3 = dec.model.owed.w3;
+        for (; i + 64u <= len_min; i += 64u) GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
+        // rebuild the low record still owed the way statement A does: v204-v207 then hold what is to be written
+        asm volatile(
+            "v_add_u32 %[lbw], %[lbw], %[lincb]\n\t"
+            "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t"
+            "v_add_u32 %[lcc], %[lcc], %[lx]\n\t"
+            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t"
+            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t"
+            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t"
+            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t"
+            "v_addc_co_u32 v204, vcc, v204, 0, %[lma]\n\t"
+            "v_add_u32 v205, 1, v205\n\t"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx)
+            : [lincb] "v"(lincb), [lma] "s"(lma), [lmc] "s"(lmc), "v"(r0), "v"(r1), "v"(r2), "v"(r3)
+            : "vcc");
+    }
+    // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
+    //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
+    for (; i + 64u <= len_max; i += 64u) {
+        if (i + 64u <= dec.ulen) GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_PLAIN)
+    }
+#undef GPUAR_DECODE_BLOCK
+#undef GPUAR_DECODE_RUN
     // hand the state back to the plain step (the tail below, finish())
     dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
     dec.model.owed.w0 = o0, dec.model.owed.w1 = o1, dec.model.owed.w2 = o2, dec.model.owed.w3 = o3;

