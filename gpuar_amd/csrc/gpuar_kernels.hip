@@ -472,69 +472,80 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_addc_co_u32 v204, %[mj], v204, 0, %[lma]\n\t" \
             "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */
 
-#define GPUAR_STEP_TAIL(NP_OUT) \
-        dec.off = static_cast<uint32_t>((((static_cast<uint64_t>(dec.off - dn) << 32) | window) << n) >> 32); \
-        dec.owed_bits = n; \
-        NP_OUT = np;
+// The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
+// w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
+// for at its previous refill and asks for the next one -- from its 64-byte ring in LDS (piece = 16 bytes,
+// address = ring + piece * 1024 + byte inside the piece; decode_wave keeps the ring filled).  The ds_read of
+// `ahead` is never waited for by itself: it is older than the record read of this very symbol, whose
+// s_waitcnt lgkmcnt(1) (LDS operations complete in order) comes long before the next refill reads `ahead`.
+#define GPUAR_STREAM_TEXT \
+            "v_sub_co_u32 %[rem], vcc, %[rem], %[n]\n\t" /* borrow: w0 ran out */ \
+            "v_and_b32 %[rem], 31, %[rem]\n\t" \
+            "s_and_saveexec_b64 %[sx], vcc\n\t" \
+            "s_cbranch_execz 1f\n\t" \
+            "v_mov_b32 %[w0], %[w1]\n\t" \
+            "v_perm_b32 %[w1], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
+            "v_and_b32 %[t0], 0x30, %[next]\n\t" \
+            "v_lshl_add_u32 %[t0], %[t0], 6, %[ring]\n\t" \
+            "v_and_or_b32 %[t0], %[next], 12, %[t0]\n\t" \
+            "ds_read_b32 %[ahead], %[t0]\n\t" \
+            "v_add_u32 %[next], 4, %[next]\n\t" \
+            "1:\n\t" \
+            "s_or_b64 exec, exec, %[sx]\n\t" \
+            "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t" /* the next 32 stream bits */
+
+// off' = ((off - dn) : window) << n, upper half (off lives in v217, the window in v216)
+#define GPUAR_OFF_TEXT \
+            "v_sub_u32 v217, v217, %[dn]\n\t" \
+            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t"
+
+#define GPUAR_STEP_OPERANDS_COMMON \
+              [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), \
+              [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
+              [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [bad] "+v"(bad_min), [oaddr] "+v"(oaddr), \
+              [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next16), [n] "+v"(nbits), \
+              [dn] "=&v"(dn), [bw] "=&v"(bw), [cc] "=&v"(cc), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), \
+              [a] "=&v"(a), [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
+
+#define GPUAR_STEP_LOCALS \
+        uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, a, wd, h, e; \
+        unsigned long long m0, m1, ma, mc, mj, sx;
 
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
-        uint32_t R0, R, np, am, t0, t1, t2; \
-        unsigned long long m0, m1; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL \
-            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
-              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
-              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
-            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
-              [lincb] "v"(lincb), [lma] "s"(lma), [lmc] "s"(lmc), "v"(r0), "v"(r1), "v"(r2), "v"(r3) \
-            : "vcc", "memory", "v204", "v205", "v206", "v207"); \
-        /* shadow of read #1: the stream reader catches up with the previous symbol */ \
-        dec.skip(dec.owed_bits); \
-        const uint32_t window = dec.peek(); \
-        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e; \
-        unsigned long long ma, mc, mj; \
-        asm volatile(GPUAR_BC_TEXT GPUAR_BC_TAIL_CARRIED \
-            : [R] "+v"(R), [np] "+v"(np), [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [kff] "+v"(kff), [bad] "+v"(bad_min), \
-              [oaddr] "=&v"(oaddr), [dn] "=&v"(dn), [n] "=&v"(n), [bw] "=&v"(bw), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), \
-              [t2] "=&v"(t2), [t3] "=&v"(t3), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), [a] "=&v"(a), \
-              [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), \
-              [lbw] "=&v"(lbw), [lcc] "=&v"(lcc), [lincb] "=&v"(lincb), [lx] "=&v"(lx), [lma] "=&s"(lma), [lmc] "=&s"(lmc), \
-              "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
-            : [R0] "v"(R0), [off] "v"(dec.off), [col] "v"(col_lds), [am] "v"(am), [k64k] "v"(k64k), \
-              [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)) \
-            : "vcc", "memory", "v208", "v209", "v210", "v211"); \
-        GPUAR_STEP_TAIL(NP_OUT) \
+        GPUAR_STEP_LOCALS \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_STREAM_TEXT GPUAR_BC_TEXT GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
+            : GPUAR_STEP_OPERANDS_COMMON, \
+              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "+s"(lma), [lmc] "+s"(lmc), \
+              "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) \
+            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [bsw] "s"(bswap_sel) \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v216"); \
+        NP_OUT = np; \
     }
 
 #define GPUAR_DECODE_SYMBOL_PLAIN(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
-        uint32_t R0, R, np, am, t0, t1, t2; \
-        unsigned long long m0, m1; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL \
-            : [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
-              [m0] "=&s"(m0), [m1] "=&s"(m1), [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
-              "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) \
-            : [off] "v"(dec.off), [rng] "v"(dec.range), [tot] "s"((K_TOTAL)), [col] "v"(col_lds), [oaddr] "v"(oaddr), \
-              "v"(o0), "v"(o1), "v"(o2), "v"(o3) \
-            : "vcc", "memory"); \
-        dec.skip(dec.owed_bits); \
-        const uint32_t window = dec.peek(); \
-        uint32_t dn, n, bw, cc, t3, pa, pb, pc, ps, a, wd, h, e, lbw_, lcc_; \
-        unsigned long long ma, mc, mj, lma_, lmc_; \
-        asm volatile(GPUAR_BC_TEXT GPUAR_BC_TAIL_PLAIN \
-            : [R] "+v"(R), [np] "+v"(np), [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [kff] "+v"(kff), [bad] "+v"(bad_min), \
-              [oaddr] "=&v"(oaddr), [dn] "=&v"(dn), [n] "=&v"(n), [bw] "=&v"(bw), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), \
-              [t2] "=&v"(t2), [t3] "=&v"(t3), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), [a] "=&v"(a), \
-              [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), \
+        GPUAR_STEP_LOCALS \
+        uint32_t lbw_, lcc_; \
+        unsigned long long lma_, lmc_; \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_STREAM_TEXT GPUAR_BC_TEXT GPUAR_OFF_TEXT GPUAR_BC_TAIL_PLAIN \
+            : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
-              "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
-            : [R0] "v"(R0), [off] "v"(dec.off), [col] "v"(col_lds), [am] "v"(am), [k64k] "v"(k64k), \
-              [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)) \
-            : "vcc", "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"); \
-        GPUAR_STEP_TAIL(NP_OUT) \
+              "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) \
+            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [bsw] "s"(bswap_sel) \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216"); \
+        NP_OUT = np; \
     }
 
-// `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit
+// LDS of a decoder workgroup (one wavefront): the 64 models and the 64 stream rings, 40 KiB -> four per CU.
+constexpr uint32_t kRingPieces = 4;                        // 16-byte pieces per lane: 64 bytes of stream
+constexpr uint32_t kDecodeLdsQuads = (kDecodeRecords + kRingPieces) * kLanes;
+
+// `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit.  `col` = this lane's 16-byte
+// column of the workgroup's LDS: 36 model records, then the 4 pieces of its stream ring, 1024 bytes apart.
 __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
                                             uint8_t *out, bool live) {
     DecoderLane<10> dec;
@@ -551,64 +562,107 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
 
     // ---- state of the hand-scheduled step ----
     const uint32_t col_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(col));   // LDS byte address of this lane's column
-    register uint32_t q0 asm("v200");          // mid record as read (statement A issues the read, BC waits for it)
-    register uint32_t q1 asm("v201");
-    register uint32_t q2 asm("v202");
-    register uint32_t q3 asm("v203");
+    const uint32_t ring_lds = col_lds + (kDecodeRecords << 10);                         // ... and of its stream ring
+    uint8_t *ring = col + (kDecodeRecords << 10);
     register uint32_t o0 asm("v204");          // PLAIN: low record of the previous symbol, rebuilt, not yet written back
     register uint32_t o1 asm("v205");
     register uint32_t o2 asm("v206");
     register uint32_t o3 asm("v207");
-    register uint32_t r0 asm("v212");          // CARRIED: low record of the previous symbol as read; statement A rebuilds it
+    register uint32_t r0 asm("v212");          // CARRIED: low record of the previous symbol as read; the next step rebuilds it
     register uint32_t r1 asm("v213");          // (path in lma / lincb / lx / lmc) and writes it back in the shadow of its read
     register uint32_t r2 asm("v214");
     register uint32_t r3 asm("v215");
+    register uint32_t offr asm("v217");        // code - lo; v216:v217 is the pair the 64-bit shift of the window works on
+    offr = dec.off;
+    uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
     uint32_t oaddr = col_lds + dec.model.owed.rec - SubtreeModel<10>::kLowBase;      // the write carries offset:4096
     // min over the symbols of (off - range) mod 2^32: a value below 0xFFFF0000 means that some symbol met
     // off >= range, a code value no symbol owns (range <= 2^16, so off < range wraps to >= 0xFFFF0000)
     uint32_t bad_min = 0xFFFFFFFFu;
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u;
+    uint32_t bswap_sel;
+    asm volatile("s_mov_b32 %0, 0x00010203" : "=s"(bswap_sel));     // (through asm: a known constant would be spliced in as a literal)
 
-    // The per-symbol reciprocals (Recip, 8 bytes per symbol) come as ONE 64-byte scalar load per EIGHT symbols,
-    // issued eight symbols before its first use into the register set the run after next will read (two
-    // sets, taken in turn: no copies); the model total is simply counted up.  Why so far ahead: a scalar load
-    // that misses its cache goes to L2 like everything else, and while the wavefronts stream their packets
-    // in and their output out, that round trip takes several symbol steps -- with the load issued one group
-    // of four symbols ahead every wavefront sat out ~170 of 790 cycles per symbol (measured by taking the
-    // vector loads and stores out: tools/kind_timing.py).  A scalar load counts in lgkmcnt like
-    // the LDS operations but may return out of order, so (a) the waits of the symbol step are all of the form
-    // "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" -- satisfied as soon as the read is
-    // back whether or not the scalar load is -- and (b) the next load is issued AFTER the first symbol of a run,
-    // i.e. behind the compiler's own lgkmcnt(0) for the run's constants, so that wait never catches it.
-    typedef uint32_t ConstRun __attribute__((ext_vector_type(16)));         // {mul, shift} x 8 symbols
-    const ConstRun *const_runs = reinterpret_cast<const ConstRun *>(g_recip.r);
-    constexpr uint32_t kLastRun = kPacket / 8u - 1u;
-#define GPUAR_DECODE_RUN(SYMBOL, K, TOTAL0, NEXT_LOAD, W0, W1)                                                       \
-    {                                                                                                                \
-        uint32_t word, np_out;                                                                                       \
-        SYMBOL((TOTAL0), K[0], K[1], np_out) word = np_out;                                                          \
-        NEXT_LOAD;                                                                                                   \
-        SYMBOL((TOTAL0) + 1u, K[2], K[3], np_out) word |= np_out << 8;                                               \
-        SYMBOL((TOTAL0) + 2u, K[4], K[5], np_out) word |= np_out << 16;                                              \
-        SYMBOL((TOTAL0) + 3u, K[6], K[7], np_out) word |= np_out << 24;                                              \
-        block[W0] = ~word; /* np holds the COMPLEMENTED symbol bits */                                               \
-        SYMBOL((TOTAL0) + 4u, K[8], K[9], np_out) word = np_out;                                                     \
-        SYMBOL((TOTAL0) + 5u, K[10], K[11], np_out) word |= np_out << 8;                                             \
-        SYMBOL((TOTAL0) + 6u, K[12], K[13], np_out) word |= np_out << 16;                                            \
-        SYMBOL((TOTAL0) + 7u, K[14], K[15], np_out) word |= np_out << 24;                                            \
-        block[W1] = ~word;                                                                                           \
+    // ---- the stream ring ----
+    // The step takes its stream dwords from a per-lane ring of 64 bytes in LDS, NOT from memory: a load from
+    // memory that every symbol waits for (whichever lane asked for it) makes the symbol as long as a
+    // round trip to L2, which at full load is LONGER than the step itself (~740 against ~600 cycles).
+    // The ring is refilled here, every four symbols, in pieces of 16 bytes that are asked for one phase
+    // (four symbols) before they are written to LDS: the vector-memory wait is for something issued
+    // ~2500 cycles ago.  Offsets are counted from base16 = base rounded down to 16 bytes, so pieces are
+    // aligned (an aligned piece that holds one readable byte never crosses a page); past the end of what
+    // may be read the last such piece is repeated (a well-formed packet decodes the same whatever follows).
+    // A lane consumes at most 31 bits per symbol = 15.5 bytes per phase, a phase brings 16: asking for
+    // piece P once the reader is within 48 bytes of it keeps >= 17 bytes in LDS ahead of the reader, and
+    // the piece P overwrites (P - 64) has been read completely by then.
+    const uint32_t skew16 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) & 15u);
+    const uint8_t *base16 = base - skew16;
+    uint32_t next16 = dec.next + skew16;                         // offset from base16 of the dword after `ahead`
+    const uint32_t last_piece = (dec.last + skew16) & ~15u;
+    uint32_t fill = (next16 & ~15u) + 16u * kRingPieces;         // offset of the next piece to ask for
+    constexpr uint32_t kNoPiece = 0xFFFFFFFFu;
+    uint32_t quad_at = kNoPiece;                                 // the piece in flight (asked for at the previous phase)
+    Quad quad;
+    quad.w[0] = quad.w[1] = quad.w[2] = quad.w[3] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRingPieces; ++k) {
+        const uint32_t at = (next16 & ~15u) + 16u * k;
+        const Quad q = load128(base16 + (at < last_piece ? at : last_piece));
+        store128(ring + ((at & 0x30u) << 6), q.w[0], q.w[1], q.w[2], q.w[3]);
     }
+#define GPUAR_RING_PHASE                                                                                             \
+    {                                                                                                                \
+        if (quad_at != kNoPiece) store128(ring + ((quad_at & 0x30u) << 6), quad.w[0], quad.w[1], quad.w[2], quad.w[3]); \
+        if (fill - next16 <= 48u) {                                                                                  \
+            quad = load128(base16 + (fill < last_piece ? fill : last_piece));                                        \
+            quad_at = fill;                                                                                          \
+            fill += 16u;                                                                                             \
+        } else {                                                                                                     \
+            quad_at = kNoPiece;                                                                                      \
+        }                                                                                                            \
+    }
+
+    // The per-symbol reciprocals (Recip: 8 bytes per symbol, wave-uniform) reach the symbol step WITHOUT scalar
+    // loads: one coalesced vector load per block of 64 symbols puts symbol j's pair into lane j of two
+    // registers, a whole block ahead, and each step picks its pair with two v_readlane; the model total is
+    // simply counted up.  Scalar loads were the costliest thing in this loop: a scalar load that misses its
+    // cache goes to L2 like everything else, and while 1024 wavefronts stream their packets in and their
+    // output out that round trip is thousands of cycles; it counts in lgkmcnt with the LDS operations, can
+    // only be waited for with lgkmcnt(0), and even issued eight symbols ahead of its use it cost ~80 of
+    // ~720 cycles per symbol (one group ahead: ~175 of 830; measured by taking the table walk out,
+    // tools/kind_timing.py).  The waits of the symbol step have the form "an LDS read, one LDS operation
+    // behind it, s_waitcnt lgkmcnt(1)", which holds whatever else is in flight.
+    const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    Recip recip_now, recip_next = g_recip.r[lane_id];                       // lane j: the pair of symbol i + j
+    // (every lane takes part in this rotation, also one that sits the block out: it may hold the pair of a symbol)
+#define GPUAR_ROTATE_RECIPS                                                                                          \
+    {                                                                                                                \
+        recip_now = recip_next;                                                                                      \
+        const uint32_t ahead_at = i + 64u + lane_id;                                                                 \
+        recip_next = g_recip.r[ahead_at < kPacket ? ahead_at : kPacket - 1u];                                        \
+    }
+#define GPUAR_MUL_OF(J) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(J)))
+#define GPUAR_SHIFT_OF(J) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.shift), static_cast<int>(J)))
 #define GPUAR_DECODE_BLOCK(SYMBOL)                                                                                   \
     {                                                                                                                \
         uint32_t block[16];                                                                                          \
-        ConstRun ka = const_runs[i >> 3];                                                                            \
-        _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 4u) {                                                 \
-            const uint32_t run = (i >> 3) + (g >> 1); /* wave-uniform */                                             \
-            const uint32_t total0 = 256u + i + 4u * g;                                                               \
-            ConstRun kb;                                                                                             \
-            GPUAR_DECODE_RUN(SYMBOL, ka, total0, kb = const_runs[run + 1u], g, g + 1u)                              \
-            GPUAR_DECODE_RUN(SYMBOL, kb, total0 + 8u, ka = const_runs[run + 2u <= kLastRun ? run + 2u : kLastRun], g + 2u, g + 3u) \
+        _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 2u) {                                                 \
+            const uint32_t j0 = 4u * g; /* wave-uniform: first symbol of this run inside the block */               \
+            const uint32_t total0 = 256u + i + j0;                                                                   \
+            uint32_t word, np_out;                                                                                   \
+            SYMBOL(total0, GPUAR_MUL_OF(j0), GPUAR_SHIFT_OF(j0), np_out) word = np_out;                              \
+            SYMBOL(total0 + 1u, GPUAR_MUL_OF(j0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), np_out) word |= np_out << 8;         \
+            SYMBOL(total0 + 2u, GPUAR_MUL_OF(j0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), np_out) word |= np_out << 16;        \
+            SYMBOL(total0 + 3u, GPUAR_MUL_OF(j0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), np_out) word |= np_out << 24;        \
+            block[g] = ~word; /* np holds the COMPLEMENTED symbol bits */                                            \
+            GPUAR_RING_PHASE                                                                                         \
+            SYMBOL(total0 + 4u, GPUAR_MUL_OF(j0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), np_out) word = np_out;               \
+            SYMBOL(total0 + 5u, GPUAR_MUL_OF(j0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), np_out) word |= np_out << 8;         \
+            SYMBOL(total0 + 6u, GPUAR_MUL_OF(j0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), np_out) word |= np_out << 16;        \
+            SYMBOL(total0 + 7u, GPUAR_MUL_OF(j0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), np_out) word |= np_out << 24;        \
+            block[g + 1u] = ~word;                                                                                   \
+            GPUAR_RING_PHASE                                                                                         \
         }                                                                                                            \
         uint4 *dst = reinterpret_cast<uint4 *>(out + i);                                                             \
         _Pragma("unroll") for (uint32_t v = 0; v < 4; ++v)                                                           \
@@ -626,8 +680,11 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
         asm volatile("s_mov_b64 %0, 0\n\ts_mov_b64 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\tv_mov_b32 %4, 0\n\tv_mov_b32 %5, 0"
                      : "=s"(lma), "=s"(lmc), "=v"(lincb), "=v"(lx), "=v"(r0), "=v"(r2));
         lbw = dec.model.owed.w0, r1 = dec.model.owed.w1 - 1u, lcc = dec.model.owed.w2, r3 = dec.model.owed.w3;
-        for (; i + 64u <= len_min; i += 64u) GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
-        // rebuild the low record still owed the way statement A does: v204-v207 then hold what is to be written
+        for (; i + 64u <= len_min; i += 64u) {
+            GPUAR_ROTATE_RECIPS
+            GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
+        }
+        // rebuild the low record still owed the way the step does: v204-v207 then hold what is to be written
         asm volatile(
             "v_add_u32 %[lbw], %[lbw], %[lincb]\n\t"
             "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t"
@@ -645,11 +702,19 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
     //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
     for (; i + 64u <= len_max; i += 64u) {
+        GPUAR_ROTATE_RECIPS
         if (i + 64u <= dec.ulen) GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_PLAIN)
     }
 #undef GPUAR_DECODE_BLOCK
-#undef GPUAR_DECODE_RUN
-    // hand the state back to the plain step (the tail below, finish())
+#undef GPUAR_MUL_OF
+#undef GPUAR_SHIFT_OF
+#undef GPUAR_ROTATE_RECIPS
+#undef GPUAR_RING_PHASE
+    // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dec.ahead) : : "memory");
+    dec.next = next16 - skew16;
+    dec.off = offr;
+    dec.owed_bits = nbits;
     dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
     dec.model.owed.w0 = o0, dec.model.owed.w1 = o1, dec.model.owed.w2 = o2, dec.model.owed.w3 = o3;
     dec.bad = dec.bad || bad_min < 0xFFFF0000u;
@@ -670,12 +735,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
 
 __global__ void __launch_bounds__(kLanes)
 decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint4 tree[kDecodeRecords * kLanes];    // 36 KiB: 36 records x 64 lanes x 16 B
+    __shared__ uint4 lds[kDecodeLdsQuads];             // 40 KiB: (36 records + 4 ring pieces) x 64 lanes x 16 B
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const uint8_t *group_slots = slots + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);      // wave-uniform
-    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), group_slots, lane * kSlot, (lane + 1u) * kSlot,
+    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), group_slots, lane * kSlot, (lane + 1u) * kSlot,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
@@ -684,7 +749,7 @@ decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8
 __global__ void __launch_bounds__(kLanes)
 decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offsets,
                      uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint4 tree[kDecodeRecords * kLanes];
+    __shared__ uint4 lds[kDecodeLdsQuads];
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
@@ -696,7 +761,7 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint64_t left = offsets[n_packets] - first;                       // bytes from the base to the end of the stream
     const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
     const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
-    decode_wave(reinterpret_cast<uint8_t *>(tree + lane), group_stream, pkt_off, limit_off,
+    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), group_stream, pkt_off, limit_off,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
