@@ -1,15 +1,37 @@
+// gpu_compressor.cpp -- host pipeline of the GPU path.
+//
+// The reference moves one 8704-byte packet per memcpy and per fwrite, all on one thread
+// (/root/reference/src/gpu_compressor.cpp:134-171, 280-340).  Here the file is cut into CHUNKS of
+// whole packets (a multiple of 64, 64 MiB of input by default) and every chunk goes down a lane:
+//
+//     pread (sliced over helper threads, straight into pinned memory)  ->  H2D  ->  kernels  ->  D2H
+//         ->  its place in the output file is known  ->  pwrite (sliced, straight from pinned memory)
+//
+// Each GPU runs kLanesPerDevice lanes at once, each a host thread with its own HIP stream and buffers,
+// so the file read of one chunk, the PCIe copies and kernels of another and the file write of a third
+// overlap without any explicit scheduling; chunks are dealt to the GPUs round-robin (chunk c -> device
+// c mod G), which is the contiguous-packet-range sharding of SURVEY.md section 8(e) at chunk grain.
+// The only serial step is the running output offset: a chunk may be written once every chunk before
+// it has said how many bytes it produced (OrderedOffsets).  Decoding works the same way in the other
+// direction; where the packets of a chunk start is known from the index trailer (packet_index.hpp) or
+// from a scanner thread that walks the packet headers (`off += clen`, 4 bytes read per packet) ahead of
+// the lanes.  The files produced are byte-identical to those of the reference's loop from byte 20 on.
 #include "gpu_compressor.hpp"
 
 #include <hip/hip_runtime_api.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "file_header.hpp"
-#include "packet_index.hpp"
 #include "gpuar_hip.h"
+#include "packet_index.hpp"
 
 namespace gip {
 
@@ -17,6 +39,9 @@ namespace {
 
 constexpr size_t kPacket = GPUAR_PACKET_BYTES;
 constexpr size_t kSlot = GPUAR_SLOT_BYTES;
+constexpr size_t kLanesPerDevice = 3;      // chunks in flight per GPU: one reading, one on the GPU, one writing
+constexpr size_t kIoSlice = 16u << 20;     // a pread / pwrite is cut into slices of this size, one helper thread each
+constexpr size_t kIoThreads = 4;           // ... at most this many at a time per lane
 
 void hip_check(hipError_t e, const char *what) {
     // same message shape as src/gpu_compressor.cpp:189-192
@@ -26,9 +51,83 @@ void gpuar_check(int code, const char *what) {
     if (code != GPUAR_OK) throw std::runtime_error(std::string("Fail to execute kernel code: ") + what + ": " + gpuar_hip_error_string(code));
 }
 
+// pread / pwrite of a large range, cut into slices that run on a few threads: one thread moves
+// page-cache pages at 2-5 GB/s, which is what bounded the previous, single-threaded pipeline.
+template <bool kWrite>
+void sliced_io(int fd, uint8_t *buf, size_t n, uint64_t at, const char *error) {
+    const size_t slices = std::max<size_t>(1, std::min(kIoThreads, (n + kIoSlice - 1) / kIoSlice));
+    const size_t per = ((n + slices - 1) / slices + 4095) & ~static_cast<size_t>(4095);
+    std::atomic<bool> failed{false};
+    auto run = [&](size_t k) {
+        size_t done = std::min(n, k * per);
+        const size_t end = std::min(n, done + per);
+        while (done < end) {
+            const ssize_t got = kWrite ? ::pwrite(fd, buf + done, end - done, static_cast<off_t>(at + done))
+                                       : ::pread(fd, buf + done, end - done, static_cast<off_t>(at + done));
+            if (got <= 0) {
+                failed = true;
+                return;
+            }
+            done += static_cast<size_t>(got);
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (size_t k = 1; k < slices; ++k) helpers.emplace_back(run, k);
+    run(0);
+    for (auto &h : helpers) h.join();
+    if (failed) throw std::runtime_error(error);
+}
+
+// The one serial quantity of the pipeline: where the output of chunk c starts = what all chunks
+// before it produced.  A lane calls take(c, n): it blocks until chunks 0..c-1 have called, returns
+// the running total before its own n bytes and lets chunk c+1 go.
+class OrderedOffsets {
+  public:
+    explicit OrderedOffsets(uint64_t start) : total(start) {}
+    uint64_t take(size_t chunk, uint64_t bytes) {
+        std::unique_lock<std::mutex> hold(lock);
+        turn.wait(hold, [&] { return aborted || next == chunk; });
+        if (aborted) throw std::runtime_error("pipeline stopped");
+        const uint64_t mine = total;
+        total += bytes;
+        ++next;
+        turn.notify_all();
+        return mine;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> hold(lock);
+        aborted = true;
+        turn.notify_all();
+    }
+    uint64_t sum() {
+        std::lock_guard<std::mutex> hold(lock);
+        return total;
+    }
+
+  private:
+    std::mutex lock;
+    std::condition_variable turn;
+    size_t next = 0;
+    uint64_t total;
+    bool aborted = false;
+};
+
 }  // namespace
 
-// Everything one GPU needs for one round of `cap` packets.
+// Keeps the first failure of any lane and tells the others to stop.
+struct GPUCompressor::Failure {
+    std::mutex lock;
+    std::exception_ptr first;
+    std::atomic<bool> stop{false};
+    void set(std::exception_ptr e) {
+        std::lock_guard<std::mutex> hold(lock);
+        // "pipeline stopped" is what the lanes woken by an abort throw: never the cause
+        if (!first) first = e;
+        stop = true;
+    }
+};
+
+// Everything one lane needs for one chunk of `cap` packets.
 struct GPUCompressor::DeviceBuffers {
     int device = 0;
     size_t cap = 0;                 // packets
@@ -41,10 +140,7 @@ struct GPUCompressor::DeviceBuffers {
     uint8_t *h_plain = nullptr;     // pinned, cap * 8192
     uint8_t *h_stream = nullptr;    // pinned, cap * 8704 (+16)
     uint64_t *h_offsets = nullptr;  // pinned, cap + 1
-    // per-round results
-    size_t n_plain = 0, n_packets = 0, n_stream = 0;
-    float kernel_ms = 0;
-    std::exception_ptr failure;
+    double kernel_ms = 0;           // summed over the chunks this lane handled
 
     void allocate(int dev, size_t packets) {
         device = dev;
@@ -77,10 +173,9 @@ struct GPUCompressor::DeviceBuffers {
         cap = 0;
     }
 
-    // h_plain[0..n_plain) -> h_stream[0..n_stream), h_offsets[0..n_packets]
-    void encodeRound() {
-        hip_check(hipSetDevice(device), "hipSetDevice");
-        n_packets = (n_plain + kPacket - 1) / kPacket;
+    // h_plain[0..n_plain) -> h_stream[0..n_stream), h_offsets[0..n_packets]; returns n_stream
+    size_t encodeChunk(size_t n_plain) {
+        const size_t n_packets = (n_plain + kPacket - 1) / kPacket;
         hip_check(hipMemcpyAsync(d_plain, h_plain, n_plain, hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipEventRecord(t0, stream), "event");
         gpuar_check(gpuar_hip_encode(d_plain, n_plain, d_slots, stream), "gpuar_hip_encode");
@@ -88,18 +183,17 @@ struct GPUCompressor::DeviceBuffers {
         hip_check(hipEventRecord(t1, stream), "event");
         hip_check(hipMemcpyAsync(h_offsets, d_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
-        n_stream = static_cast<size_t>(h_offsets[n_packets]);
+        const size_t n_stream = static_cast<size_t>(h_offsets[n_packets]);
         hip_check(hipMemcpyAsync(h_stream, d_stream, n_stream, hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
-        hip_check(hipEventElapsedTime(&kernel_ms, t0, t1), "event");
-        uint32_t flags = 0;
-        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
-        if (flags & GPUAR_STATUS_SLOT_OVERFLOW) throw std::runtime_error("a packet outgrew its 8704-byte slot");
+        float ms = 0;
+        hip_check(hipEventElapsedTime(&ms, t0, t1), "event");
+        kernel_ms += ms;
+        return n_stream;
     }
 
     // h_stream[0..n_stream) with h_offsets[0..n_packets] -> h_plain[0..n_packets*8192)
-    void decodeRound() {
-        hip_check(hipSetDevice(device), "hipSetDevice");
+    void decodeChunk(size_t n_stream, size_t n_packets) {
         hip_check(hipMemcpyAsync(d_stream, h_stream, n_stream, hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipMemcpyAsync(d_offsets, h_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipEventRecord(t0, stream), "event");
@@ -107,10 +201,9 @@ struct GPUCompressor::DeviceBuffers {
         hip_check(hipEventRecord(t1, stream), "event");
         hip_check(hipMemcpyAsync(h_plain, d_plain, n_packets * kPacket, hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
-        hip_check(hipEventElapsedTime(&kernel_ms, t0, t1), "event");
-        uint32_t flags = 0;
-        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
-        if (flags & GPUAR_STATUS_BAD_PACKET) throw std::runtime_error("Incorrect file format");
+        float ms = 0;
+        hip_check(hipEventElapsedTime(&ms, t0, t1), "event");
+        kernel_ms += ms;
     }
 };
 
@@ -132,26 +225,23 @@ void GPUCompressor::releaseBuffers() {
     buffers.clear();
 }
 
-// Two buffer sets per device: while the GPUs work on one round, the host reads the next round's
-// input into the other set and writes the previous round's output.  Sized for the job at hand: a
-// file of `total_packets` needs at most ceil(total / devices) packets per device per round, and a
-// job that fits one round never touches the second set -- pinned allocations are what a short run
-// of the CLI spends most of its time on.
+// kLanesPerDevice buffer sets per device, sized for the job at hand: a file of `total_packets` is cut
+// into chunks of at most batchPackets packets, small enough that every lane of every device gets one
+// (whole wavefronts: multiples of 64 packets).  A lane's buffers are allocated when it first gets a
+// chunk -- pinned allocations are what a short run of the CLI spends most of its time on.
 void GPUCompressor::ensureBuffers(size_t total_packets) {
     const size_t G = devices.size();
-    const size_t per_dev = ((total_packets + G - 1) / G + 63) / 64 * 64;
-    const size_t cap = std::max<size_t>(64, std::min(batchPackets, per_dev));
-    const bool one_round = total_packets <= G * cap;
-    const bool have = buffers.size() == 2 * G && !buffers.empty() && buffers[0]->cap >= cap && buffers[0]->cap <= batchPackets &&
-                      (one_round || buffers[G]->cap == buffers[0]->cap);
+    const size_t lanes = G * kLanesPerDevice;
+    const size_t share = ((total_packets + lanes - 1) / lanes + 63) / 64 * 64;
+    const size_t cap = std::max<size_t>(64, std::min(batchPackets, share));
+    const bool have = buffers.size() == lanes && !buffers.empty() && chunkPackets == cap;
     if (have) return;
     releaseBuffers();
-    for (int set = 0; set < 2; ++set)
-        for (int dev : devices) {
-            DeviceBuffers *b = new DeviceBuffers();
-            buffers.push_back(b);
-            if (set == 0 || !one_round) b->allocate(dev, cap);
-        }
+    chunkPackets = cap;
+    for (size_t l = 0; l < lanes; ++l) {
+        buffers.push_back(new DeviceBuffers());
+        buffers.back()->device = devices[l / kLanesPerDevice];
+    }
 }
 
 void GPUCompressor::chooseDevice(const int id) {
@@ -176,23 +266,24 @@ void GPUCompressor::useDevices(const int n) {
     for (int d = 0; d < n; ++d) devices.push_back(d % count);
 }
 
-namespace {
+// Runs `work(lane, buffers, failure)` on every lane (lanes g*kLanesPerDevice .. belong to device g) and
+// rethrows the first failure.  `work` pulls chunk numbers until there are none left.
+template <typename Work>
+void GPUCompressor::runLanes(Work &&work) {
+    Failure failure;
+    std::vector<std::thread> threads;
+    for (size_t l = 0; l < buffers.size(); ++l)
+        threads.emplace_back([&, l] {
+            try {
+                work(l, *buffers[l], failure);
+            } catch (...) {
+                failure.set(std::current_exception());
+            }
+        });
+    for (auto &t : threads) t.join();
+    if (failure.first) std::rethrow_exception(failure.first);
+}
 
-// One round in flight: the device work of every GPU on one buffer set, each on its own host thread.
-struct Round {
-    std::vector<std::thread> workers;
-    bool active = false;
-    void join() {
-        for (auto &w : workers) w.join();
-        workers.clear();
-    }
-};
-
-}  // namespace
-
-// Pipeline over rounds r = 0, 1, ... with buffer set r & 1:
-//   read input of round r  ||  GPUs run round r-1   (then)   GPUs run round r  ||  write output of round r-1
-// File order is kept because rounds, and devices within a round, are drained in order.
 CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     CompressionInfo info;
     monitor->reset();
@@ -200,93 +291,128 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     io_timer.reset();
     io_timer.start();
     openFiles();
-    double kernel_ms_total = 0;
-    Round in_flight;
     try {
         info.uncompressedFileSize = getFileSize(openFile);
-        ensureBuffers((info.uncompressedFileSize + kPacket - 1) / kPacket);
-        const size_t roundPackets = buffers[0]->cap;       // packets per device per round
-        if (std::fseek(saveFile, FileHeader::HEADER_LENGTH, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
-        info.compressedFileSize = FileHeader::HEADER_LENGTH;
+        const size_t total_packets = (info.uncompressedFileSize + kPacket - 1) / kPacket;
+        ensureBuffers(total_packets);
         const size_t G = devices.size();
-        size_t remaining = info.uncompressedFileSize;
-        int set = 0;
-        std::vector<uint16_t> all_clens;       // for the optional index trailer
-        auto write_out = [&](int which) {      // output of the finished round that used buffer set `which`
-            float slowest = 0;
-            for (size_t g = 0; g < G; ++g) {
-                DeviceBuffers *b = buffers[which * G + g];
-                if (!b->n_plain) continue;
-                if (b->failure) std::rethrow_exception(b->failure);
-                slowest = std::max(slowest, b->kernel_ms);
-                if (b->n_stream && std::fwrite(b->h_stream, 1, b->n_stream, saveFile) != b->n_stream)
-                    throw std::runtime_error("Write compressed data to output file failed");
-                if (writeIndex)
-                    for (size_t p = 0; p < b->n_packets; ++p)
-                        all_clens.push_back(static_cast<uint16_t>(b->h_offsets[p + 1] - b->h_offsets[p]));
-                info.compressedFileSize += b->n_stream;
-                info.processedUncompressedSize += b->n_plain;
-            }
-            kernel_ms_total += slowest;
-            monitor->updateProgress(&info);
-        };
-        while (remaining > 0) {
-            // contiguous packet ranges, device order = file order
-            const size_t round_bytes = std::min(remaining, G * roundPackets * kPacket);
-            const size_t round_packets = (round_bytes + kPacket - 1) / kPacket;
-            const size_t per_dev = ((round_packets + G - 1) / G + 63) / 64 * 64;      // whole wavefronts
-            size_t given = 0;
-            for (size_t g = 0; g < G; ++g) {       // overlaps with the previous round's GPU work
-                DeviceBuffers *b = buffers[set * G + g];
-                if (!b->cap) b->allocate(devices[g], roundPackets);       // second set, first needed now
-                b->n_plain = std::min(round_bytes - given, std::min(per_dev, b->cap) * kPacket);
-                b->failure = nullptr;
-                if (b->n_plain && std::fread(b->h_plain, 1, b->n_plain, openFile) != b->n_plain)
-                    throw std::runtime_error("Read input file failed");
-                given += b->n_plain;
-            }
-            std::vector<std::thread> next;
-            const bool had_previous = in_flight.active;
-            if (had_previous) in_flight.join();    // GPUs are free again
-            for (size_t g = 0; g < G; ++g) {
-                DeviceBuffers *b = buffers[set * G + g];
-                if (b->n_plain) next.emplace_back([b] {
-                    try {
-                        b->encodeRound();
-                    } catch (...) {
-                        b->failure = std::current_exception();
+        const size_t chunk_bytes = chunkPackets * kPacket;
+        const size_t n_chunks = (info.uncompressedFileSize + chunk_bytes - 1) / chunk_bytes;
+        const int in_fd = fileno(openFile), out_fd = fileno(saveFile);
+        OrderedOffsets place(FileHeader::HEADER_LENGTH);
+        std::vector<std::vector<uint16_t>> chunk_clens(writeIndex ? n_chunks : 0);     // for the optional index trailer
+        std::vector<std::atomic<size_t>> next_of_device(G);
+        for (auto &n : next_of_device) n = 0;
+        std::mutex progress_lock;
+
+        runLanes([&](size_t lane, DeviceBuffers &b, Failure &failure) {
+            const size_t g = lane / kLanesPerDevice;
+            try {
+                for (;;) {
+                    // contiguous packet ranges in file order, dealt round-robin: chunk c belongs to device c mod G
+                    const size_t c = g + G * next_of_device[g].fetch_add(1);
+                    if (c >= n_chunks || failure.stop) break;
+                    if (!b.cap) b.allocate(b.device, chunkPackets);
+                    hip_check(hipSetDevice(b.device), "hipSetDevice");
+                    const uint64_t at = static_cast<uint64_t>(c) * chunk_bytes;
+                    const size_t n_plain = static_cast<size_t>(std::min<uint64_t>(chunk_bytes, info.uncompressedFileSize - at));
+                    sliced_io<false>(in_fd, b.h_plain, n_plain, at, "Read input file failed");
+                    const size_t n_stream = b.encodeChunk(n_plain);
+                    uint32_t flags = 0;
+                    gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
+                    if (flags & GPUAR_STATUS_SLOT_OVERFLOW) throw std::runtime_error("a packet outgrew its 8704-byte slot");
+                    const size_t n_packets = (n_plain + kPacket - 1) / kPacket;
+                    if (writeIndex) {
+                        chunk_clens[c].resize(n_packets);
+                        for (size_t p = 0; p < n_packets; ++p) chunk_clens[c][p] = static_cast<uint16_t>(b.h_offsets[p + 1] - b.h_offsets[p]);
                     }
-                });
+                    const uint64_t out_at = place.take(c, n_stream);      // every chunk before this one has said its size
+                    sliced_io<true>(out_fd, b.h_stream, n_stream, out_at, "Write compressed data to output file failed");
+                    std::lock_guard<std::mutex> hold(progress_lock);
+                    info.processedUncompressedSize += n_plain;
+                    monitor->updateProgress(&info);
+                }
+            } catch (...) {
+                failure.set(std::current_exception());
+                place.abort();
             }
-            in_flight.workers = std::move(next);
-            in_flight.active = true;
-            if (had_previous) write_out(set ^ 1);   // this file write overlaps with the new round's GPU work
-            remaining -= round_bytes;
-            set ^= 1;
+        });
+
+        info.compressedFileSize = static_cast<size_t>(place.sum());
+        if (writeIndex) {
+            std::vector<uint16_t> all;
+            for (const auto &v : chunk_clens) all.insert(all.end(), v.begin(), v.end());
+            if (std::fseek(saveFile, static_cast<long>(info.compressedFileSize), SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
+            PacketIndex::write(saveFile, all);
+            if (std::fflush(saveFile) != 0) throw std::runtime_error("Write packet index failed");
         }
-        if (in_flight.active) {
-            in_flight.join();
-            write_out(set ^ 1);
-        }
-        if (writeIndex) PacketIndex::write(saveFile, all_clens);
         FileHeader header;
         header.setCompressedFileSize(info.compressedFileSize);
         header.setUncompressedFileSize(info.uncompressedFileSize);
-        if (std::fseek(saveFile, 0, SEEK_SET) != 0) throw std::runtime_error("Seek file failed");
-        if (std::fwrite(header.getData(), FileHeader::HEADER_LENGTH, 1, saveFile) != 1)
+        if (::pwrite(out_fd, header.getData(), FileHeader::HEADER_LENGTH, 0) != FileHeader::HEADER_LENGTH)
             throw std::runtime_error("Write data to file failed");
         closeFiles();
     } catch (...) {
-        in_flight.join();
         closeFiles();
         throw;
     }
     io_timer.stop();
-    // "Compute time" = kernels + their sync, as src/gpu_compressor.cpp:184-194; the rest is I/O
-    info.processTime = kernel_ms_total;
-    info.ioTime = std::max(0.0, io_timer.value() - kernel_ms_total);
+    finishTimes(info);
     return info;
 }
+
+// "Compute time" = kernels + their sync, as src/gpu_compressor.cpp:184-194 -- with several lanes and
+// devices working at once, the busiest device's total; the rest of the wall time is I/O.
+void GPUCompressor::finishTimes(CompressionInfo &info) {
+    std::vector<double> per_device(devices.size(), 0.0);
+    for (size_t l = 0; l < buffers.size(); ++l) {
+        per_device[l / kLanesPerDevice] += buffers[l]->kernel_ms;
+        buffers[l]->kernel_ms = 0;
+    }
+    info.processTime = *std::max_element(per_device.begin(), per_device.end());
+    info.ioTime = std::max(0.0, io_timer.value() - info.processTime);
+}
+
+namespace {
+
+// Where the packets of each chunk sit in the stream.  Filled by the index trailer in one go, or by
+// the scanner thread as it walks the headers; lanes wait for the chunk they are about to take.
+struct ChunkMap {
+    struct Chunk {
+        uint64_t begin = 0, end = 0;     // file offsets of the chunk's first byte / one past its last
+        size_t n_packets = 0;
+    };
+    std::mutex lock;
+    std::condition_variable more;
+    std::vector<Chunk> chunks;
+    bool complete = false;
+    std::exception_ptr failure;
+
+    void push(const Chunk &c) {
+        std::lock_guard<std::mutex> hold(lock);
+        chunks.push_back(c);
+        more.notify_all();
+    }
+    void finish(std::exception_ptr e = nullptr) {
+        std::lock_guard<std::mutex> hold(lock);
+        complete = true;
+        failure = e;
+        more.notify_all();
+    }
+    // false: there is no chunk c
+    bool get(size_t c, Chunk &out) {
+        std::unique_lock<std::mutex> hold(lock);
+        more.wait(hold, [&] { return c < chunks.size() || complete; });
+        if (c < chunks.size()) {
+            out = chunks[c];
+            return true;
+        }
+        if (failure) std::rethrow_exception(failure);
+        return false;
+    }
+};
+
+}  // namespace
 
 CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
     CompressionInfo info;
@@ -295,8 +421,6 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
     io_timer.reset();
     io_timer.start();
     openFiles();
-    double kernel_ms_total = 0;
-    Round in_flight;
     try {
         FileHeader header;
         const size_t fileSize = getFileSize(openFile);
@@ -306,122 +430,133 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         // every packet but the last holds 8192 bytes; a packet is at least 4 bytes long, which bounds a lying header
         ensureBuffers(std::min((info.uncompressedFileSize + kPacket - 1) / kPacket, fileSize / GPUAR_PACKET_HEADER_BYTES + 1));
         const size_t G = devices.size();
-        const size_t stream_end = streamEnd(info, fileSize);
-        size_t file_pos = FileHeader::HEADER_LENGTH;
+        const uint64_t stream_end = streamEnd(info, fileSize);
+        const int in_fd = fileno(openFile), out_fd = fileno(saveFile);
         // packet lengths from the index trailer when the file has one (packet_index.hpp)
         std::vector<uint16_t> index;
         const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, stream_end, fileSize, index);
-        size_t next_packet = 0;
-        bool more = file_pos < stream_end;
-        int set = 0;
-        auto write_out = [&](int which) {
-            float slowest = 0;
-            for (size_t g = 0; g < G; ++g) {
-                DeviceBuffers *b = buffers[which * G + g];
-                if (!b->n_packets) continue;
-                if (b->failure) std::rethrow_exception(b->failure);
-                slowest = std::max(slowest, b->kernel_ms);
-                // Every packet says how many bytes it holds (u16 at +2); all but the file's last one hold
-                // 8192 (src/gpu_compressor.cpp:326-331).  The lengths written come from the packets, not
-                // from the header's size field: a file written by the reference carries garbage in the
-                // upper half of that field (src/file_header.hpp:31-36), and --host decodes by ulen too.
-                size_t run_begin = 0, run_bytes = 0;       // contiguous bytes of h_plain not yet written
-                auto flush = [&] {
-                    if (run_bytes && std::fwrite(b->h_plain + run_begin, 1, run_bytes, saveFile) != run_bytes)
-                        throw std::runtime_error("Write uncompressed data to output file failed");
-                    info.processedUncompressedSize += run_bytes;
-                    run_bytes = 0;
-                };
-                for (size_t p = 0; p < b->n_packets; ++p) {
-                    const uint8_t *pkt = b->h_stream + b->h_offsets[p];
-                    const size_t ulen = std::min<size_t>(kPacket, pkt[2] | (static_cast<size_t>(pkt[3]) << 8));
-                    if (run_bytes == 0) run_begin = p * kPacket;
-                    run_bytes += ulen;
-                    if (ulen != kPacket) flush();          // a short packet ends the contiguous run
+
+        ChunkMap map;
+        std::thread scanner;
+        std::atomic<bool> stop_scan{false};
+        if (indexed) {                   // prefix sums of the stored lengths (already checked against the stream size)
+            uint64_t at = FileHeader::HEADER_LENGTH;
+            for (size_t p = 0; p < index.size();) {
+                ChunkMap::Chunk c;
+                c.begin = at;
+                while (p < index.size() && c.n_packets < chunkPackets) {
+                    const size_t clen = index[p++];
+                    if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot) throw std::runtime_error("Invalid file length");
+                    at += clen;
+                    ++c.n_packets;
                 }
-                flush();
+                c.end = at;
+                map.push(c);
             }
-            kernel_ms_total += slowest;
-            monitor->updateProgress(&info);
-        };
-        while (more) {
-            // Fill each device with up to cap packets.  One bulk read per device: with an index the
-            // range and its offsets come from the stored lengths (prefix sum); without one the bytes
-            // are read first and `off += clen` is walked in memory (src/gpu_compressor.cpp:299-312
-            // walks it through the file, two reads per packet), then the file is wound back to the
-            // end of the last whole packet.
-            for (size_t g = 0; g < G; ++g) {
-                DeviceBuffers *b = buffers[set * G + g];
-                if (!b->cap) b->allocate(devices[g], buffers[g]->cap);    // second set, first needed now (the header understated the file)
-                b->n_packets = 0;
-                b->n_stream = 0;
-                b->h_offsets[0] = 0;
-                b->failure = nullptr;
-                if (!more) continue;
-                if (indexed) {
-                    while (next_packet < index.size() && b->n_packets < b->cap) {
-                        const size_t clen = index[next_packet++];
-                        if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot) throw std::runtime_error("Invalid file length");
-                        b->n_stream += clen;
-                        b->h_offsets[++b->n_packets] = b->n_stream;
-                    }
-                    if (b->n_stream && std::fread(b->h_stream, 1, b->n_stream, openFile) != b->n_stream)
-                        throw std::runtime_error("Invalid file length");
-                } else {
-                    const size_t want = std::min(stream_end - file_pos, b->cap * kSlot);
-                    if (std::fread(b->h_stream, 1, want, openFile) != want) throw std::runtime_error("Invalid file length");
-                    size_t off = 0;
-                    while (off < want && b->n_packets < b->cap) {
-                        if (want - off < GPUAR_PACKET_HEADER_BYTES) {
-                            if (file_pos + want == stream_end) throw std::runtime_error("Incorrect file format");
-                            break;                     // header cut by the read window: next round
+            map.finish();
+        } else {
+            // the header walk of src/gpu_compressor.cpp:299-312 (`off += clen`), four bytes read per packet, ahead of the lanes
+            scanner = std::thread([&] {
+                try {
+                    uint64_t at = FileHeader::HEADER_LENGTH;
+                    while (at < stream_end && !stop_scan) {
+                        ChunkMap::Chunk c;
+                        c.begin = at;
+                        while (at < stream_end && c.n_packets < chunkPackets) {
+                            uint8_t h[GPUAR_PACKET_HEADER_BYTES];
+                            if (stream_end - at < sizeof h || ::pread(in_fd, h, sizeof h, static_cast<off_t>(at)) != static_cast<ssize_t>(sizeof h))
+                                throw std::runtime_error("Incorrect file format");
+                            const size_t clen = getPacketSize(h);
+                            if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot || at + clen > stream_end)
+                                throw std::runtime_error("Invalid file length");
+                            at += clen;
+                            ++c.n_packets;
                         }
-                        const size_t clen = getPacketSize(b->h_stream + off);
-                        if (clen < GPUAR_PACKET_HEADER_BYTES || clen > kSlot || file_pos + off + clen > stream_end)
-                            throw std::runtime_error("Invalid file length");
-                        if (off + clen > want) break;  // packet cut by the read window: next round
-                        off += clen;
-                        b->h_offsets[++b->n_packets] = off;
+                        c.end = at;
+                        map.push(c);
                     }
-                    b->n_stream = off;
-                    if (off != want && std::fseek(openFile, static_cast<long>(file_pos + off), SEEK_SET) != 0)
-                        throw std::runtime_error("Seek file failed");
+                    map.finish();
+                } catch (...) {
+                    map.finish(std::current_exception());
                 }
-                file_pos += b->n_stream;
-                more = file_pos < stream_end;
-            }
-            std::vector<std::thread> next;
-            const bool had_previous = in_flight.active;
-            if (had_previous) in_flight.join();
-            for (size_t g = 0; g < G; ++g) {
-                DeviceBuffers *b = buffers[set * G + g];
-                if (b->n_packets) next.emplace_back([b] {
-                    try {
-                        b->decodeRound();
-                    } catch (...) {
-                        b->failure = std::current_exception();
+            });
+        }
+
+        OrderedOffsets place(0);
+        std::vector<std::atomic<size_t>> next_of_device(G);
+        for (auto &n : next_of_device) n = 0;
+        std::mutex progress_lock;
+        try {
+            runLanes([&](size_t lane, DeviceBuffers &b, Failure &failure) {
+                const size_t g = lane / kLanesPerDevice;
+                try {
+                    for (;;) {
+                        const size_t c = g + G * next_of_device[g].fetch_add(1);
+                        ChunkMap::Chunk chunk;
+                        if (failure.stop || !map.get(c, chunk)) break;
+                        if (!b.cap) b.allocate(b.device, chunkPackets);
+                        hip_check(hipSetDevice(b.device), "hipSetDevice");
+                        const size_t n_stream = static_cast<size_t>(chunk.end - chunk.begin);
+                        sliced_io<false>(in_fd, b.h_stream, n_stream, chunk.begin, "Invalid file length");
+                        // packet offsets inside the chunk, and what every packet says it holds (u16 at +2): all but the
+                        // file's last one hold 8192 bytes (src/gpu_compressor.cpp:326-331).  What is written comes from
+                        // the packets, not from the header's size field: a file written by the reference carries garbage
+                        // in the upper half of that field (src/file_header.hpp:31-36), and --host decodes by ulen too.
+                        uint64_t produced = 0;
+                        size_t off = 0;
+                        bool all_full = true;
+                        for (size_t p = 0; p < chunk.n_packets; ++p) {
+                            b.h_offsets[p] = off;
+                            if (n_stream - off < GPUAR_PACKET_HEADER_BYTES) throw std::runtime_error("Invalid file length");
+                            const uint8_t *pkt = b.h_stream + off;
+                            const size_t clen = getPacketSize(pkt);
+                            if (clen < GPUAR_PACKET_HEADER_BYTES || off + clen > n_stream) throw std::runtime_error("Invalid file length");
+                            const size_t ulen = std::min<size_t>(kPacket, pkt[2] | (static_cast<size_t>(pkt[3]) << 8));
+                            all_full = all_full && (ulen == kPacket || p + 1 == chunk.n_packets);
+                            produced += ulen;
+                            off += clen;
+                        }
+                        if (off != n_stream) throw std::runtime_error("Invalid file length");
+                        b.h_offsets[chunk.n_packets] = off;
+                        const uint64_t out_at = place.take(c, produced);
+                        b.decodeChunk(n_stream, chunk.n_packets);
+                        uint32_t flags = 0;
+                        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
+                        if (flags & GPUAR_STATUS_BAD_PACKET) throw std::runtime_error("Incorrect file format");
+                        if (all_full) {
+                            sliced_io<true>(out_fd, b.h_plain, static_cast<size_t>(produced), out_at, "Write uncompressed data to output file failed");
+                        } else {             // short packets inside the chunk: one write per packet
+                            uint64_t at = out_at;
+                            for (size_t p = 0; p < chunk.n_packets; ++p) {
+                                const uint8_t *pkt = b.h_stream + b.h_offsets[p];
+                                const size_t ulen = std::min<size_t>(kPacket, pkt[2] | (static_cast<size_t>(pkt[3]) << 8));
+                                if (ulen) sliced_io<true>(out_fd, b.h_plain + p * kPacket, ulen, at, "Write uncompressed data to output file failed");
+                                at += ulen;
+                            }
+                        }
+                        std::lock_guard<std::mutex> hold(progress_lock);
+                        info.processedUncompressedSize += static_cast<size_t>(produced);
+                        monitor->updateProgress(&info);
                     }
-                });
-            }
-            in_flight.workers = std::move(next);
-            in_flight.active = true;
-            if (had_previous) write_out(set ^ 1);
-            set ^= 1;
+                } catch (...) {
+                    failure.set(std::current_exception());
+                    place.abort();
+                }
+            });
+        } catch (...) {
+            stop_scan = true;
+            if (scanner.joinable()) scanner.join();
+            throw;
         }
-        if (in_flight.active) {
-            in_flight.join();
-            write_out(set ^ 1);
-        }
+        if (scanner.joinable()) scanner.join();
         info.uncompressedFileSize = info.processedUncompressedSize;     // what the packets held
         closeFiles();
     } catch (...) {
-        in_flight.join();
         closeFiles();
         throw;
     }
     io_timer.stop();
-    info.processTime = kernel_ms_total;
-    info.ioTime = std::max(0.0, io_timer.value() - kernel_ms_total);
+    finishTimes(info);
     return info;
 }
 

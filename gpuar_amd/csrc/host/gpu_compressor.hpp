@@ -1,9 +1,10 @@
 // gpu_compressor.hpp -- host pipeline of the GPU path, API as
 // src/gpu_compressor.hpp:8-39 (chooseDevice, getPacketSize, compress,
 // decompress) plus useDevices() for the multi-GPU sharding the north star
-// adds.  Internals are new: bulk pinned transfers, device-side compaction and
-// one host thread per GPU instead of the reference's per-packet memcpys
-// (src/gpu_compressor.cpp:134-171).
+// adds.  Internals are new: chunks of whole packets go down independent lanes
+// (sliced pread into pinned memory, bulk transfers, device-side compaction,
+// sliced pwrite), several lanes per GPU, instead of the reference's
+// per-packet memcpys on one thread (src/gpu_compressor.cpp:134-171).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -28,19 +29,24 @@ class GPUCompressor : public Compressor {
         return static_cast<unsigned short>(packet[0] | (packet[1] << 8));
     }
 
-    // packets each device takes per round (default 32768 = 256 MiB of input), kept a multiple of 64
-    // (whole wavefronts: compress() deals every device a multiple of 64 packets, which must fit its
-    // buffers); rounds are double-buffered, so file reads, GPU work and file writes of neighbouring rounds overlap
+    // largest chunk a lane takes at a time, in packets (default 8192 = 64 MiB of input: measured best of 32/64/128/256 MiB, tools/cli_sweep.sh), kept a multiple
+    // of 64 (whole wavefronts); a file is cut into chunks no larger than this, small enough that every lane
+    // of every device gets one
     void setBatchPackets(size_t n) { batchPackets = n < 64 ? 64 : n / 64 * 64; }
 
   private:
     struct DeviceBuffers;
+    struct Failure;
     std::vector<int> devices;
-    std::vector<DeviceBuffers *> buffers;
-    size_t batchPackets = 32768;
+    std::vector<DeviceBuffers *> buffers;      // one per lane, device-major
+    size_t batchPackets = 8192;
+    size_t chunkPackets = 0;                   // chunk size of the job the buffers were set up for
 
     void releaseBuffers();
     void ensureBuffers(size_t total_packets);
+    template <typename Work>
+    void runLanes(Work &&work);
+    void finishTimes(CompressionInfo &info);
 };
 
 }  // namespace gip

@@ -52,7 +52,7 @@ void usage() {
     std::cout << "--device      specify GPU device, otherwise use device 0" << std::endl;
     std::cout << "--gpus        shard the packets over this many GPUs (devices 0..K-1)" << std::endl;
     std::cout << "--threads     host threads for --host (default 1, 0 = all cores)" << std::endl;
-    std::cout << "--batch       packets per GPU per pipeline round (default 32768 = 256 MiB)" << std::endl;
+    std::cout << "--batch       largest chunk of packets a pipeline lane takes at a time (default 8192 = 64 MiB)" << std::endl;
     std::cout << "--index       (compress) append the packet-offset index trailer; decompress uses it when present" << std::endl;
     std::cout << "--nointeractive no interactive mode" << std::endl;
 }

@@ -1,20 +1,26 @@
 #!/usr/bin/env bash
-# End-to-end wall time of the gpuar CLI on the GPU box: 1 GiB uniform(42), compress / decompress,
-# with and without the packet-offset index.  Usage (via gpurun): bash tools/cli_timing.sh
+# End-to-end wall time of the gpuar CLI on the GPU box (file in the page cache -> pinned -> GPU -> pinned
+# -> file): uniform(42), compress / decompress, with and without the packet-offset index.
+# Usage (via gpurun): bash tools/cli_timing.sh [GiB, default 8]
 set -u
+G=${1:-8}
 B=gpuar_amd/bin/gpuar
 D=${TMPDIR:-/tmp}
 python3 - <<PY
 from gpuar_amd import synth
-synth.uniform(42, 1 << 30).tofile("$D/u1g.dat")
+n = int($G * (1 << 30))
+with open("$D/u.dat", "wb") as f:
+    step = 1 << 28
+    for off in range(0, n, step):
+        synth.uniform(42, min(step, n - off), offset=off).tofile(f)
 PY
-t() { local s=$(date +%s%N); "$@" > "$D/cli.log" 2>&1; local rc=$?; local e=$(date +%s%N); printf "%5d ms  rc=%d  %s | %s\n" "$(( (e - s) / 1000000 ))" "$rc" "$*" "$(grep -E 'Compute time|I/O time' "$D/cli.log" | tr -s ' ' | tr '\n' ' ')"; }
-t $B c --in=$D/u1g.dat --out=$D/u1g.gip
-t $B c --in=$D/u1g.dat --out=$D/u1g.gip
-t $B c --index --in=$D/u1g.dat --out=$D/u1g_idx.gip
-t $B d --in=$D/u1g.gip --out=$D/u1g.back
-t $B d --in=$D/u1g.gip --out=$D/u1g.back
-t $B d --in=$D/u1g_idx.gip --out=$D/u1g.back2
-t $B d --in=$D/u1g_idx.gip --out=$D/u1g.back2
-cmp $D/u1g.dat $D/u1g.back && cmp $D/u1g.dat $D/u1g.back2 && echo roundtrip-ok
-rm -f $D/u1g.dat $D/u1g.gip $D/u1g_idx.gip $D/u1g.back $D/u1g.back2
+t() { local s=$(date +%s%N); "$@" > "$D/cli.log" 2>&1; local rc=$?; local e=$(date +%s%N); local ms=$(( (e - s) / 1000000 )); printf "%6d ms  %6.2f GB/s  rc=%d  %s | %s\n" "$ms" "$(python3 -c "print($G * 1.073741824 / ($ms / 1000.0))")" "$rc" "$*" "$(grep -E 'Compute time|I/O time' "$D/cli.log" | tr -s ' ' | tr '\n' ' ')"; }
+t $B c --in=$D/u.dat --out=$D/u.gip
+t $B c --in=$D/u.dat --out=$D/u.gip
+t $B c --index --in=$D/u.dat --out=$D/u_idx.gip
+t $B d --in=$D/u.gip --out=$D/u.back
+t $B d --in=$D/u.gip --out=$D/u.back
+t $B d --in=$D/u_idx.gip --out=$D/u.back2
+t $B d --in=$D/u_idx.gip --out=$D/u.back2
+cmp $D/u.dat $D/u.back && cmp $D/u.dat $D/u.back2 && echo roundtrip-ok
+rm -f $D/u.dat $D/u.gip $D/u_idx.gip $D/u.back $D/u.back2
