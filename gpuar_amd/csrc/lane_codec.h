@@ -34,17 +34,6 @@
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // low 32 bits of (hi:lo) >> (s & 31)
 #define GPUAR_ALIGNBIT(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
-// both 16-bit halves of v shifted left by the low half of s (s <= 15), each half on its own
-#define GPUAR_PK_SHL16(v, s) ([](uint32_t v_, uint32_t s_) { uint32_t r_; asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r_) : "v"(s_), "v"(v_)); return r_; }((v), (s)))
-// x + y + (c ? 1 : 0) as ONE add-with-carry fed by the compare's lane mask (hipcc otherwise builds
-// the same value from selects and ors)
-#define GPUAR_ADDC(x, y, c) ([](uint32_t x_, uint32_t y_, bool c_) { uint32_t r_; unsigned long long co_; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r_), "=s"(co_) : "v"(x_), "v"(y_), "s"(__builtin_amdgcn_ballot_w64(c_))); return r_; }((x), (y), (c)))
-// a + low / high half-word of b in one instruction (the compiler splits it into and/shift + add when a
-// select follows); issued ahead of the compare whose result picks one of them
-#define GPUAR_ADD_LO16(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
-#define GPUAR_ADD_HI16(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
-// x is wave-uniform: keep it as ONE scalar register instead of re-deriving it from its parts at every use
-#define GPUAR_UNIFORM(x) asm("" : "+s"(x))
 // the load that produces q is issued here, before any later store (no wait is implied)
 #define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
@@ -59,11 +48,6 @@
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #define GPUAR_MAD24(a, b, c) ((a) * (b) + (c))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
-#define GPUAR_PK_SHL16(v, s) (((((v) & 0xFFFFu) << ((s) & 15u)) & 0xFFFFu) | (((((v) >> 16) << ((s) & 15u)) & 0xFFFFu) << 16))
-#define GPUAR_ADDC(x, y, c) ((x) + (y) + ((c) ? 1u : 0u))
-#define GPUAR_ADD_LO16(a, b) ((a) + ((b) & 0xFFFFu))
-#define GPUAR_ADD_HI16(a, b) ((a) + ((b) >> 16))
-#define GPUAR_UNIFORM(x) ((void)0)
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #endif
@@ -282,12 +266,14 @@ template <uint32_t kRowShift>
 using LowModeler = PartialModeler<kRowShift, 5, 3, 0, true>;        // depths 5..7 and the x == 255 term
 
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
-// State: lo and nh = 0xFFFF - hi packed as lo | nh << 16, so that both bounds
-// renormalise with the same left shift (zeros enter lo, ones enter hi).
+// State: the interval as its lower bound and its WIDTH (lo, range = hi - lo + 1): both renormalise
+// with one left shift each -- every step of writeEncodedBits (:321-367) takes the same constant off lo
+// and hi and doubles them, so hi - lo + 1 just doubles; lo' = (lo << n) & 0x7FFF (closed form above bswap32).
 // Output bits gather in a 32-bit accumulator; a full dword leaves with one
 // (predicated) store.
 struct CoderLane {
-    uint32_t p;          // lo | (0xFFFF - hi) << 16
+    uint32_t lo;         // lower bound (< 2^15 between symbols)
+    uint32_t range;      // hi - lo + 1  (2^14 < range <= 2^16 between symbols)
     uint32_t pending;    // underflow bits owed
     uint32_t acc, n;     // n (< 32) output bits, right-aligned in acc
     uint32_t pos;        // bytes stored so far after the 4-byte packet header
@@ -295,7 +281,8 @@ struct CoderLane {
     uint32_t body_off;   // ... plus this lane's byte offset of slot + 4
 
     GPUAR_LANE void open(uint8_t *uniform_base, uint32_t slot_offset) {
-        p = 0;            // lo = 0, hi = 0xFFFF  (:492-494)
+        lo = 0;           // lo = 0, hi = 0xFFFF  (:492-494)
+        range = 0x10000u;
         pending = 0;
         acc = 0;
         n = 0;
@@ -342,21 +329,17 @@ struct CoderLane {
     }
 
     GPUAR_LANE void step(uint32_t cums, Recip rc) {
-        const uint32_t lo = p & 0xFFFFu;
-        const uint32_t above = 0x10000u - lo;                 // hi + 1 - lo + nh
-        const uint32_t range = above - (p >> 16);             // hi - lo + 1
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
         const uint32_t a = lo + dn;                           // new lo
-        const uint32_t b = above - up;                        // 0xFFFF - new hi
-        // e = agreeing MSBs of new lo / new hi = leading ones of a ^ b (16 bit)
-        const uint32_t e = GPUAR_CLZ32(~((a ^ b) << 16));
-        const uint32_t a1 = (a << e) & 0xFFFFu, b1 = (b << e) & 0xFFFFu;
-        // underflow run: from bit 14 down, lo has 1 and hi has 0  <=>  a1 & b1
-        const uint32_t u = GPUAR_CLZ32(~((a1 & b1) << 17));
-        p = GPUAR_PK_SHL16(a1 | (b1 << 16), u) & 0x7FFF7FFFu;   // both halves shifted by u (<= 15), each on its own
-        // the e agreed bits (same in lo and hi): top, then `pending` copies of
-        // !top, then the rest.  Branch-free for the usual pending <= 16.
+        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+        const uint32_t h = a + wd - 1u;                       // new hi
+        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
+        const uint32_t e = GPUAR_CLZ32((((a ^ h) & 0xFFFFu) << 16) | 0xFFFFu);
+        const uint32_t u = GPUAR_CLZ32(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        const uint32_t shift = e + u;
+        lo = (a << shift) & 0x7FFFu;
+        range = wd << shift;
         // The e agreed bits (same in lo and hi) leave as: their MSB, then `pending`
         // copies of its complement, then the rest.  Inserting p complement bits
         // behind the MSB of an e-bit number A is the number A + (2^p - 1) * 2^(e-1)
@@ -380,7 +363,7 @@ struct CoderLane {
 
     GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed) {
         uint8_t *body = base + body_off;
-        const uint32_t bit14 = (p >> 14) & 1u;                // bit 14 of lo (writeRemaining :379-388)
+        const uint32_t bit14 = (lo >> 14) & 1u;               // bit 14 of lo (writeRemaining :379-388)
         put_bit_then_run(bit14, pending + 1u);
         // zero-pad to a byte boundary and store the tail (writeClose :430-439)
         const uint32_t tail_bytes = (n + 7u) >> 3;
