@@ -202,7 +202,7 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
         r = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
              "algorithmic_bytes_per_launch": algo_bytes, "traffic": t.get("hbm_bytes_per_launch")}
         # the roof that actually binds (SURVEY.md section 7 risk 1): vector-issue and wait share of the wavefronts' cycles
-        for k in ("valu_busy", "wait_frac", "valu_insts_per_symbol_step"):
+        for k in ("valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step"):
             if k in t:
                 r[k] = t[k]
         return r

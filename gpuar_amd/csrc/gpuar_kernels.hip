@@ -15,7 +15,10 @@
 //    wavefront makes the workgroup cover all four SIMDs so that roles can be
 //    dealt out per SIMD;
 //  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
-//    two 16-byte subtree records per symbol instead of walking eight levels;
+//    two 16-byte subtree records per symbol instead of walking eight levels and
+//    works on a scaled remainder (no division, borrow = path bit); the symbol step
+//    is a hand-scheduled instruction stream; the packet stream reaches it through a
+//    per-lane ring in LDS, the per-symbol constants through v_readlane;
 //  * compaction (scan + gather) and synthetic-stream generators.
 //
 // Bit-exact with the reference: same counts, same integer arithmetic, same
@@ -303,28 +306,30 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // instruction costs one issue slot of 4.2-4.7 cycles whether or not it depends on its predecessor;
 // `s_nop 0` costs a whole slot (4 cycles), `s_nop 1` two; a scalar instruction costs a slot as well;
 // ds_read_b128 comes back after ~65 cycles and holds the issue port ~12, ds_write_b128 ~20.  So the
-// step is priced in SLOTS, and the two LDS round trips are free exactly when ~15 independent
-// instructions sit behind each read.  The compiler's own schedule of lane_codec.h's step_symbol
-// spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane mask it
-// writes); the two statements below spend 103 and leave the stream reader (skip(), ~13 slots with
-// its refill branch) to the compiler, because the reader's global load has to stay visible to the
-// compiler's s_waitcnt bookkeeping.
+// step is priced in SLOTS, the two LDS round trips are free exactly when ~15 independent
+// instructions sit behind each read, and anything the wavefront has to WAIT for is pure loss: a
+// scalar load (thousands of cycles under load, and it can only be waited for with lgkmcnt(0)) or a
+// vector load the whole wavefront waits for (~720 cycles under load, longer than the step) -- the
+// loop below contains neither.  The compiler's own schedule of lane_codec.h's
+// step_symbol spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane
+// mask it writes); the statement below spends ~112 vector + 5 LDS.
 //
-//   statement A : R0 = off*total + total - 1; depths 0 and 1 (registers); write-back of the previous
-//                 symbol's low record; READ #1 (mid record) issued; register nodes bumped
-//   (C++)       : skip() of the previous symbol's bits, peek()           <- shadow of read #1
-//   statement BC: mid record: 3 decisions; READ #2 (low record) issued; mid record rebuilt and
-//                 written back                                            <- shadow of read #2
-//                 low record: 3 decisions, W = cnt*range, interval narrowed and renormalised,
-//                 low record rebuilt into the `owed` registers
-//   (C++)       : off = (off - dn : window) << n, the symbol joins the output word
+//   R0 = off*total + total - 1; depths 0 and 1 (registers); READ #1 (mid record) issued
+//       in its shadow: the previous symbol's low record rebuilt and written back, register nodes bumped,
+//       the stream window steps over the previous symbol's bits (refill from the LDS ring), peek
+//   wait; mid record: 3 decisions; READ #2 (low record) issued
+//       in its shadow: mid record rebuilt and written back
+//   wait; low record: 3 decisions, W = cnt*range; interval narrowed and renormalised;
+//       off = ((off - dn) : window) << n
 //
 // Lane masks: v_sub_co writes "went left" as its borrow; v_min keeps the remainder; the mask is
 // read two or more instructions later (path add-with-carry, selects of the next node and of the
-// record rebuild).  The four 16-byte LDS operands need aligned register quads and are pinned
-// (v200-v215); everything else is allocated by the compiler.  Results are those of
-// DecoderLane::step_symbol instruction for instruction (same integers), which the CPU tests pin
-// against the oracle; the GPU parity tests then compare this path with the oracle directly.
+// record rebuild).  The four 16-byte LDS operands need aligned register quads and the 64-bit shift a
+// pair: they are pinned (v200-v217); everything else is allocated by the compiler.  Both waits have
+// the form "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" (LDS operations of a
+// wavefront complete in order).  Results are those of DecoderLane::step_symbol (same integers), which
+// the CPU tests pin against the oracle; the GPU parity tests then compare this path with the oracle
+// directly.
 // ---------------------------------------------------------------------------
 #define GPUAR_SDWA_W0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
 #define GPUAR_SDWA_W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
@@ -332,11 +337,11 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 
 // One symbol of the hand-scheduled decoder (see above), in text pieces.  Two variants are assembled from them:
 //   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the low record of a
-//            symbol is rebuilt by the NEXT symbol's statement A, in the shadow of its LDS read, from the record as
+//            symbol is rebuilt by the NEXT symbol's step, in the shadow of its first LDS read, from the record as
 //            read (v212-v215) and the path (lane masks lma, lmc and lincb / lx) -- lane masks can only be carried
 //            from one statement to the next in scalar registers where the compiler sees uniform control flow;
 //   PLAIN    for the one wavefront of a file that holds its short last packet (lanes drop out under `if`):
-//            statement BC rebuilds the record itself into v204-v207.
+//            the step rebuilds the record itself into v204-v207.
 // They use decode_wave's locals by name.
 #define GPUAR_A_HEAD \
             "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
@@ -367,7 +372,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" \
 
 #define GPUAR_A_SHADOW_PLAIN \
-            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* the previous symbol's low record, rebuilt by its statement BC */
+            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* the previous symbol's low record, rebuilt by its own step */
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
@@ -454,12 +459,12 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
 
 #define GPUAR_BC_TAIL_CARRIED \
-         /* ---- what the next statement A needs to rebuild this low record (it does so in the shadow of its read) */ \
+         /* ---- what the next step needs to rebuild this low record (it does so in the shadow of its first read) */ \
             "v_cndmask_b32 %[lincb], 0, %[k64k], vcc\n\t" \
             "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
 
 #define GPUAR_BC_TAIL_PLAIN \
-         /* ---- low record rebuilt -> v204-v207 (written back by the next statement A) */ \
+         /* ---- low record rebuilt -> v204-v207 (written back by the next step) */ \
             "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" \
             "v_add_u32 %[lbw], %[lbw], %[t3]\n\t" \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \

@@ -42,8 +42,15 @@ def main(out_dir, tag, gib, kind="uniform"):
         f, w = avg("FETCH_SIZE") * 1024.0, avg("WRITE_SIZE") * 1024.0
         res[k] = {"fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2.0 * f + w}
         if d.get("SQ_WAVE_CYCLES"):
+            # per WAVEFRONT: share of its resident cycles in which it issued a vector instruction / sat in a wait
             res[k]["valu_busy"] = avg("SQ_ACTIVE_INST_VALU") / avg("SQ_WAVE_CYCLES")
             res[k]["wait_frac"] = avg("SQ_WAIT_ANY") / avg("SQ_WAVE_CYCLES")
+        if d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE"):
+            # per SIMD: vector-issue quad-cycles of all wavefronts over the cycles the 1024 SIMDs had (the encoder keeps
+            # four wavefronts on a SIMD, so its per-wavefront figure is a quarter of what the SIMD sees)
+            # (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; the decoder, one wavefront per SIMD, is the cross-check:
+            # both ways of counting give it the same 0.70)
+            res[k]["valu_busy_per_simd"] = avg("SQ_ACTIVE_INST_VALU") * 4.0 / (avg("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
         if d.get("SQ_INSTS_VALU"):
             res[k]["valu_insts_per_symbol_step"] = avg("SQ_INSTS_VALU") / symbol_steps
     path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
