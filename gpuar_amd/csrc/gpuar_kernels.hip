@@ -414,32 +414,34 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_addc_co_u32 v208, %[mj], v208, 0, %[ma]\n\t" \
             "ds_write_b128 %[am], v[208:211]\n\t" \
             "s_waitcnt lgkmcnt(1)\n\t" \
-         /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
+         /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16. \
+                 Z = R - V with V = scaled distance from the walk's origin to the upper end of the subtree it is in: \
+                 S * range on entry; going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
+                 and >= the old Z since p <= V); going right both R and V lose p and Z stays, while d >= 0: Z' = max_u32(Z, d). \
+                 At the leaf cumHi * range = R0 - Z: no width to carry, no select. */ \
             "v_mul_u32_u24_sdwa %[pa], v212, %[rng]" GPUAR_SDWA_W0 \
-            "v_sub_co_u32 %[t1], %[lma], %[R], %[pa]\n\t" \
-            "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_mul_u32_u24_sdwa %[ps], v213, %[rng]" GPUAR_SDWA_W0 \
+            "v_sub_co_u32 %[t1], %[lma], %[R], %[pa]\n\t" \
+            "v_sub_u32 %[t3], %[R], %[ps]\n\t" /* Z on entry */ \
+            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_cndmask_b32 %[lbw], v212, v213, %[lma]\n\t" \
             "v_cndmask_b32 %[lcc], v214, v215, %[lma]\n\t" \
             "v_mul_u32_u24_sdwa %[pb], %[lbw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_sub_u32 %[t3], %[ps], %[pa]\n\t" \
+            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
             "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[lmc], %[R], %[pc]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[pa], %[lma]\n\t" /* width of the depth-6 subtree on the path, scaled */ \
+            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
-            "v_sub_u32 %[t3], %[t3], %[pb]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[pb], vcc\n\t" /* ... of the depth-7 pair */ \
-            "v_sub_u32 %[t3], %[t3], %[pc]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[pc], %[lmc]\n\t" /* W = cnt(symbol) * range */ \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
-            "v_add_u32 %[t1], %[t0], %[t3]\n\t" /* cumHi * range */ \
+            "v_sub_u32 %[t1], %[R0], %[t3]\n\t" /* cumHi * range */ \
             "v_mul_hi_u32 %[dn], %[t0], %[mul]\n\t" \
             "v_mul_hi_u32 %[t1], %[t1], %[mul]\n\t" \
             "v_lshrrev_b32 %[dn], %[shift], %[dn]\n\t" \
