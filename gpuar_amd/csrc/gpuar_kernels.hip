@@ -84,6 +84,12 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // (plus the 4 idle ones that only meet the barriers, see encode_kernel).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPhase = 8;
+// Issue priority of the three roles (s_setprio; a SIMD hosts one wavefront of each role, from different
+// groups, and a group moves at the pace of its slowest role between two barriers).  Measured on uniform 2 GiB
+// (tools/kind_timing.py): all equal 6.14 ms; coder first 6.25; top modeler first 5.90; top > coder > low 5.70;
+// top > low > coder 5.87; with the 4-level share of the tree moved to the low modeler the same numbers with the
+// roles swapped -- whoever walks four LDS levels has to go first, the three-level modeler last.
+constexpr int kPrioTop = 3, kPrioCoder = 1, kPrioLow = 0;
 
 struct EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
@@ -244,13 +250,16 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint8_t *in = src + (live ? start : 0);
 
     if (role == 0) {
+        __builtin_amdgcn_s_setprio(kPrioTop);
         run_modeler<TopModeler<7>, 0>(lds, in, lane, len, len_min, n_phases);
     } else if (role == 1) {
+        __builtin_amdgcn_s_setprio(kPrioLow);
         run_modeler<LowModeler<7>, 1>(lds, in, lane, len, len_min, n_phases);
     } else if (role == 3) {
         for (uint32_t k = 0; k <= n_phases; ++k) lds_barrier();
     } else {
         // ------------------------------- coder -------------------------------
+        __builtin_amdgcn_s_setprio(kPrioCoder);
         // slot address = (wave-uniform base of this block's first slot) + lane * 8704
         uint8_t *block_slots = dst + group * (kLanes * kSlot);
         CoderLane coder;
