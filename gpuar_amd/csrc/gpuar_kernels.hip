@@ -9,7 +9,7 @@
 //  * encode_kernel: three working wavefronts per 64 packets -- two MODELERS
 //    (adaptive models in LDS: per lane a binary left-count tree, node-major/
 //    lane-minor so lane l always hits bank l & 31; software-pipelined walks
-//    over depths 0-4 and 5-7 that yield cumLo, cumHi and the count update)
+//    over depths 1-6 and {0, 7} that yield cumLo, cumHi and the count update)
 //    and a CODER (interval narrowing by a wave-uniform reciprocal, closed-form
 //    renormalisation, bit sink), joined by an LDS ring; a fourth, idle
 //    wavefront makes the workgroup cover all four SIMDs so that roles can be
@@ -62,11 +62,10 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // Workgroup = 4 wavefronts, three of them working on the same 64 packets (lane l
 // <-> packet 64*group + l in all three); which wavefront plays which role is
 // decided per SIMD at run time (see encode_kernel):
-//   TOP MODELER: depths 0..4 of the 64 adaptive models (depth 0 in a register,
-//           1-4 in LDS), reads the input bytes, emits its part of
-//           cumLo | cumHi << 16 per symbol;
-//   LOW MODELER: depths 5..7 (LDS) and the x == 255 term, same input, emits
-//           the other part;
+//   TOP MODELER: depths 1..6 of the 64 adaptive models (LDS), reads the input
+//           bytes, emits its part of cumLo | cumHi << 16 per symbol;
+//   LOW MODELER: depth 0 (a register), depth 7 (LDS) and the x == 255 term, same
+//           input, emits the other part (why 6 + 1: lane_codec.h at TopModeler);
 //   CODER: adds the two parts, owns the interval state and the bit sink, turns
 //           them into the packet bitstream;
 //   the fourth wavefront only meets the barriers.
@@ -264,7 +263,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint8_t *block_slots = dst + group * (kLanes * kSlot);
         CoderLane coder;
         coder.open(block_slots, lane * kSlot);
-        Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
+            Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
 #pragma unroll
         for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[j];
         for (uint32_t k = 0; k <= n_phases; ++k) {
@@ -394,13 +393,11 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_sub_u32 %[t3], %[off], %[rng]\n\t" /* off >= range: no symbol owns this code value */ \
             "v_cndmask_b32 %[bw], v200, v201, %[ma]\n\t" /* chosen child in the high half */ \
             "v_cndmask_b32 %[cc], v202, v203, %[ma]\n\t" /* its two children */ \
             "v_mul_u32_u24_sdwa %[t0], %[bw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_min_u32 %[bad], %[bad], %[t3]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
             "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
@@ -448,6 +445,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
+            "v_min_u32 %[bad], %[bad], %[t3]\n\t" /* Z >= 0 at the leaf: no symbol owns this code value */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_sub_u32 %[t1], %[R0], %[t3]\n\t" /* cumHi * range */ \
@@ -592,8 +590,9 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     offr = dec.off;
     uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
     uint32_t oaddr = col_lds + dec.model.owed.rec - SubtreeModel<10>::kLowBase;      // the write carries offset:4096
-    // min over the symbols of (off - range) mod 2^32: a value below 0xFFFF0000 means that some symbol met
-    // off >= range, a code value no symbol owns (range <= 2^16, so off < range wraps to >= 0xFFFF0000)
+    // min over the symbols of Z at the leaf (as u32).  A symbol owns the code value iff the remainder ends below
+    // the upper end of its leaf, Z = R - V < 0, i.e. >= 2^31 as u32 (|Z| < 2^30); a code value beyond the model's
+    // total (off >= range, where the reference stops decoding, :873-877) walks right everywhere and ends with Z >= 0
     uint32_t bad_min = 0xFFFFFFFFu;
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u;
@@ -733,7 +732,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     dec.owed_bits = nbits;
     dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
     dec.model.owed.w0 = o0, dec.model.owed.w1 = o1, dec.model.owed.w2 = o2, dec.model.owed.w3 = o3;
-    dec.bad = dec.bad || bad_min < 0xFFFF0000u;
+    dec.bad = dec.bad || bad_min < 0x80000000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
     const uint32_t part_from = dec.ulen & ~63u;

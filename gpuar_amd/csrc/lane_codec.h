@@ -21,8 +21,13 @@
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define GPUAR_LANE __device__ __forceinline__
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
+// leading zeros of a value that is never 0 (plain v_ffbh_u32: no guard for the all-zero case)
+#define GPUAR_CLZ32_NZ(x) static_cast<uint32_t>(__builtin_clz(x))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
 #define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
+// ((a ^ b) << 16) | 0xFFFF in ONE instruction: the xor lands in the high half of a register whose low half
+// is preset to 0xFFFF (kff must hold 0xFFFF in its low half; its high half is scratch)
+#define GPUAR_XOR_HI(kff, a, b) ([](uint32_t &k_, uint32_t a_, uint32_t b_) { asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(k_) : "v"(a_), "v"(b_)); return k_; }((kff), (a), (b)))
 // bit-field mask ((1 << w) - 1) << off, w and off taken mod 32: one instruction
 #define GPUAR_BFM(w, off) ([](uint32_t w_, uint32_t o_) { uint32_t r_; asm("v_bfm_b32 %0, %1, %2" : "=v"(r_) : "v"(w_), "v"(o_)); return r_; }((w), (off)))
 // the same where hipcc cannot see the 24-bit bound by itself (it would emit and + v_mul_lo_u32)
@@ -41,6 +46,8 @@
 #else
 #define GPUAR_LANE inline
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
+#define GPUAR_CLZ32_NZ(x) static_cast<uint32_t>(__builtin_clz(x))
+#define GPUAR_XOR_HI(kff, a, b) ((((a) ^ (b)) << 16) | 0xFFFFu)
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
@@ -260,25 +267,32 @@ struct PartialModeler {
     }
 };
 
+// How the tree is dealt to the two modelers (measured on the GPU, uniform 2 GiB): the wavefront
+// that issues first (the "top" modeler, highest priority) spends its time waiting for LDS round trips and has
+// issue slots to spare, so it takes six of the seven LDS-resident depths; the other one keeps depth 0 in a
+// register, depth 7 and the x == 255 term.  4 + 3 depths: 5.71 ms; 5 + 2: 5.43; 6 + 1 (this): 5.36; 7 + 0: 5.75.
 template <uint32_t kRowShift>
-using TopModeler = PartialModeler<kRowShift, 1, 4, 1, false>;       // depths 0..4 (depth 0 in a register)
+using TopModeler = PartialModeler<kRowShift, 1, 6, 0, false>;       // depths 1..6
 template <uint32_t kRowShift>
-using LowModeler = PartialModeler<kRowShift, 5, 3, 0, true>;        // depths 5..7 and the x == 255 term
+using LowModeler = PartialModeler<kRowShift, 7, 1, 1, true>;        // depth 0 (register), depth 7 and the x == 255 term
 
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
 // State: the interval as its lower bound and its WIDTH (lo, range = hi - lo + 1): both renormalise
 // with one left shift each -- every step of writeEncodedBits (:321-367) takes the same constant off lo
 // and hi and doubles them, so hi - lo + 1 just doubles; lo' = (lo << n) & 0x7FFF (closed form above bswap32).
-// Output bits gather in a 32-bit accumulator; a full dword leaves with one
-// (predicated) store.
+// Output bits gather in a 32-bit accumulator; a full dword leaves with one (predicated) store.
+// (A 64-bit accumulator needs fewer instructions but 64-bit shifts on every symbol: measured 4 % slower.)
 struct CoderLane {
     uint32_t lo;         // lower bound (< 2^15 between symbols)
     uint32_t range;      // hi - lo + 1  (2^14 < range <= 2^16 between symbols)
     uint32_t pending;    // underflow bits owed
-    uint32_t acc, n;     // n (< 32) output bits, right-aligned in acc
-    uint32_t pos;        // bytes stored so far after the 4-byte packet header
-    uint8_t *base;       // same pointer in every lane of a wavefront (scalar register on the GPU) ...
-    uint32_t body_off;   // ... plus this lane's byte offset of slot + 4
+    uint32_t acc;        // the n (< 32) waiting output bits, right-aligned
+    uint32_t n;
+    uint32_t at;         // offset from `base` of the next dword to store
+    uint32_t last;       // offset of the last dword of the slot: stores beyond it land there
+    uint32_t kff;        // low half 0xFFFF, high half scratch (GPUAR_XOR_HI)
+    uint8_t *base;       // same pointer in every lane of a wavefront (scalar register on the GPU)
+    uint32_t body_off;   // this lane's byte offset of slot + 4
 
     GPUAR_LANE void open(uint8_t *uniform_base, uint32_t slot_offset) {
         lo = 0;           // lo = 0, hi = 0xFFFF  (:492-494)
@@ -286,25 +300,26 @@ struct CoderLane {
         pending = 0;
         acc = 0;
         n = 0;
-        pos = 0;
+        kff = 0xFFFFu;
         base = uniform_base;
         body_off = slot_offset + kHdr;
+        at = body_off;
+        last = slot_offset + kSlot - 4u;
     }
 
     // append `count` (<= 32) bits, MSB first.  Straight-line except for the
     // one predicated region around the store.  A packet that outgrows its slot
     // keeps overwriting the slot's last dword (never beyond it); finish() sees
-    // pos > limit and reports the overflow.
+    // at > last and reports the overflow.
     GPUAR_LANE void put(uint32_t bits, uint32_t count) {
         const uint32_t total = n + count;                       // <= 63
+        // right-aligned accumulator; the oldest 32 bits of acc:bits by one funnel shift
         const uint32_t left_aligned = bits << ((32u - count) & 31u);
-        // the oldest 32 bits of acc:bits (a funnel shift; n < 32)
-        const uint32_t word = static_cast<uint32_t>(((static_cast<uint64_t>(acc) << 32) | left_aligned) >> n);
+        const uint32_t word = GPUAR_ALIGNBIT(acc, left_aligned, n);
         acc = (acc << (count & 31u)) | bits;                    // right if nothing leaves
         if (total >= 32u) {
-            const uint32_t at = pos < kSlot - kHdr - 4u ? pos : kSlot - kHdr - 4u;
-            store32(base + (body_off + at), bswap32(word));
-            pos += 4u;
+            store32(base + (at < last ? at : last), bswap32(word));
+            at += 4u;
             acc = bits & GPUAR_BFM(total, 0u);                  // the total-32 youngest bits stay, all from `bits`
         }
         n = total & 31u;
@@ -333,10 +348,11 @@ struct CoderLane {
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
         const uint32_t a = lo + dn;                           // new lo
         const uint32_t wd = up - dn;                          // new hi - new lo + 1
-        const uint32_t h = a + wd - 1u;                       // new hi
-        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
-        const uint32_t e = GPUAR_CLZ32((((a ^ h) & 0xFFFFu) << 16) | 0xFFFFu);
-        const uint32_t u = GPUAR_CLZ32(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        const uint32_t h = a + wd - 1u;                       // new hi (<= 0xFFFF: the interval only ever shrinks)
+        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32);
+        // neither argument of the two counts can be 0 (ones are shifted in behind the bits that matter)
+        const uint32_t e = GPUAR_CLZ32_NZ(GPUAR_XOR_HI(kff, a, h));
+        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
         const uint32_t shift = e + u;
         lo = (a << shift) & 0x7FFFu;
         range = wd << shift;
@@ -366,6 +382,7 @@ struct CoderLane {
         const uint32_t bit14 = (lo >> 14) & 1u;               // bit 14 of lo (writeRemaining :379-388)
         put_bit_then_run(bit14, pending + 1u);
         // zero-pad to a byte boundary and store the tail (writeClose :430-439)
+        const uint32_t pos = at - body_off;                   // bytes stored (or attempted) after the header
         const uint32_t tail_bytes = (n + 7u) >> 3;
         const uint32_t word = n ? (acc << (32u - n)) : 0u;
         uint32_t clen = pos + tail_bytes + kHdr;
