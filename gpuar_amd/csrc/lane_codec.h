@@ -17,7 +17,6 @@
 #include <string.h>
 
 #include "gpuar_hip.h"
-
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define GPUAR_LANE __device__ __forceinline__
 #define GPUAR_CLZ32(x) static_cast<uint32_t>(__clz(static_cast<int>(x)))
@@ -316,12 +315,34 @@ struct CoderLane {
         // right-aligned accumulator; the oldest 32 bits of acc:bits by one funnel shift
         const uint32_t left_aligned = bits << ((32u - count) & 31u);
         const uint32_t word = GPUAR_ALIGNBIT(acc, left_aligned, n);
+#if defined(__HIP_DEVICE_COMPILE__)
+        acc = (acc << (count & 31u)) | bits;                    // right if nothing leaves
+        {
+            // the predicated region by hand: lanes with a full dword store it; NO branch around it (some lane
+            // has a full dword on almost every call, and a branch costs this wavefront more than the region)
+            const unsigned long long full = __builtin_amdgcn_ballot_w64(total >= 32u);
+            unsigned long long saved;
+            uint32_t t_addr, t_word, t_mask;
+            asm volatile(
+                "s_and_saveexec_b64 %[sx], %[m]\n\t"
+                "v_min_u32 %[ta], %[at], %[last]\n\t"
+                "v_perm_b32 %[tw], 0, %[word], %[sel]\n\t"
+                "global_store_dword %[ta], %[tw], %[base]\n\t"
+                "v_add_u32 %[at], 4, %[at]\n\t"
+                "v_bfm_b32 %[tm], %[total], 0\n\t"
+                "v_and_b32 %[acc], %[bits], %[tm]\n\t"
+                "s_or_b64 exec, exec, %[sx]"
+                : [at] "+v"(at), [acc] "+v"(acc), [ta] "=&v"(t_addr), [tw] "=&v"(t_word), [tm] "=&v"(t_mask), [sx] "=&s"(saved)
+                : [m] "s"(full), [last] "v"(last), [word] "v"(word), [sel] "s"(0x00010203u), [base] "s"(base), [total] "v"(total), [bits] "v"(bits));
+        }
+#else
         acc = (acc << (count & 31u)) | bits;                    // right if nothing leaves
         if (total >= 32u) {
             store32(base + (at < last ? at : last), bswap32(word));
             at += 4u;
             acc = bits & GPUAR_BFM(total, 0u);                  // the total-32 youngest bits stay, all from `bits`
         }
+#endif
         n = total & 31u;
     }
 
@@ -364,9 +385,9 @@ struct CoderLane {
         const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
         const uint32_t em1 = e - 1u;
         const bool shift_out = e != 0u;
-        const bool long_run = shift_out && pending > 16u;     // rare: more than 16 underflow bits owed
         uint32_t bits = agreed + GPUAR_BFM(pending, em1);
         uint32_t count = e + pending;
+        const bool long_run = shift_out & (pending > 16u);    // rare: more than 16 underflow bits owed (one mask, one branch)
         if (long_run) {
             const uint32_t top = (agreed >> (em1 & 31u)) & 1u;
             put_bit_then_run(top, pending);
@@ -376,7 +397,6 @@ struct CoderLane {
         put(shift_out ? bits : 0u, shift_out ? count : 0u);
         pending = (shift_out ? 0u : pending) + u;
     }
-
     GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed) {
         uint8_t *body = base + body_off;
         const uint32_t bit14 = (lo >> 14) & 1u;               // bit 14 of lo (writeRemaining :379-388)
