@@ -488,8 +488,10 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
-// for at its previous refill and asks for the next one -- from its 64-byte ring in LDS (piece = 16 bytes,
-// address = ring + piece * 1024 + byte inside the piece; decode_wave keeps the ring filled).  The ds_read of
+// for at its previous refill and asks for the next one -- from its 64-byte ring in LDS (dword-major, lane-minor:
+// dword d of lane l at ring region + 256 * d + 4 * l, so the 64 lanes of a read hit 64 different banks whatever
+// dwords they are at; `next` is the reader's byte offset times 64, i.e. already 256 * dword index; decode_wave
+// keeps the ring filled).  The ds_read of
 // `ahead` is never waited for by itself: it is older than the record read of this very symbol, whose
 // s_waitcnt lgkmcnt(1) (LDS operations complete in order) comes long before the next refill reads `ahead`.
 #define GPUAR_STREAM_TEXT \
@@ -499,11 +501,9 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "s_cbranch_execz 1f\n\t" \
             "v_mov_b32 %[w0], %[w1]\n\t" \
             "v_perm_b32 %[w1], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
-            "v_and_b32 %[t0], 0x30, %[next]\n\t" \
-            "v_lshl_add_u32 %[t0], %[t0], 6, %[ring]\n\t" \
-            "v_and_or_b32 %[t0], %[next], 12, %[t0]\n\t" \
+            "v_and_or_b32 %[t0], %[next], %[kf00], %[ring]\n\t" /* ring + 256 * (dword index mod 16) */ \
             "ds_read_b32 %[ahead], %[t0]\n\t" \
-            "v_add_u32 %[next], 4, %[next]\n\t" \
+            "v_add_u32 %[next], 0x100, %[next]\n\t" \
             "1:\n\t" \
             "s_or_b64 exec, exec, %[sx]\n\t" \
             "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t" /* the next 32 stream bits */
@@ -518,7 +518,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
               [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), \
               [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
               [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [bad] "+v"(bad_min), [oaddr] "+v"(oaddr), \
-              [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next16), [n] "+v"(nbits), \
+              [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), [n] "+v"(nbits), \
               [dn] "=&v"(dn), [bw] "=&v"(bw), [cc] "=&v"(cc), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), \
               [a] "=&v"(a), [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
 
@@ -534,7 +534,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
               [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "+s"(lma), [lmc] "+s"(lmc), \
               "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [bsw] "s"(bswap_sel) \
+              [k64k] "v"(k64k), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v216"); \
         NP_OUT = np; \
     }
@@ -549,7 +549,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
               "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [bsw] "s"(bswap_sel) \
+              [k64k] "v"(k64k), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
@@ -559,8 +559,9 @@ constexpr uint32_t kRingPieces = 4;                        // 16-byte pieces per
 constexpr uint32_t kDecodeLdsQuads = (kDecodeRecords + kRingPieces) * kLanes;
 
 // `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit.  `col` = this lane's 16-byte
-// column of the workgroup's LDS: 36 model records, then the 4 pieces of its stream ring, 1024 bytes apart.
-__device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
+// column of the workgroup's LDS (36 model records, 1024 bytes apart); `ring` = this lane's dword 0 in the 4 KiB
+// stream-ring region behind the records (16 dwords per lane, 256 bytes apart; the region is 4 KiB-aligned).
+__device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
                                             uint8_t *out, bool live) {
     DecoderLane<10> dec;
     dec.open(col, base, pkt_off, limit_off, live);
@@ -576,8 +577,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
 
     // ---- state of the hand-scheduled step ----
     const uint32_t col_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(col));   // LDS byte address of this lane's column
-    const uint32_t ring_lds = col_lds + (kDecodeRecords << 10);                         // ... and of its stream ring
-    uint8_t *ring = col + (kDecodeRecords << 10);
+    const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));  // ... and of dword 0 of its stream ring
     register uint32_t o0 asm("v204");          // PLAIN: low record of the previous symbol, rebuilt, not yet written back
     register uint32_t o1 asm("v205");
     register uint32_t o2 asm("v206");
@@ -596,8 +596,9 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     uint32_t bad_min = 0xFFFFFFFFu;
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u;
-    uint32_t bswap_sel;
+    uint32_t bswap_sel, ring_wrap;
     asm volatile("s_mov_b32 %0, 0x00010203" : "=s"(bswap_sel));     // (through asm: a known constant would be spliced in as a literal)
+    asm volatile("s_movk_i32 %0, 0xf00" : "=s"(ring_wrap));        // 256 * 15: the ring's dword index, scaled
 
     // ---- the stream ring ----
     // The step takes its stream dwords from a per-lane ring of 64 bytes in LDS, NOT from memory: a load from
@@ -613,23 +614,30 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
     // the piece P overwrites (P - 64) has been read completely by then.
     const uint32_t skew16 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) & 15u);
     const uint8_t *base16 = base - skew16;
-    uint32_t next16 = dec.next + skew16;                         // offset from base16 of the dword after `ahead`
+    const uint32_t next16 = dec.next + skew16;                   // offset from base16 of the dword after `ahead` ...
+    uint32_t next64 = next16 << 6;                               // ... carried times 64: bits 8-11 = 256 * (dword index mod 16)
     const uint32_t last_piece = (dec.last + skew16) & ~15u;
     uint32_t fill = (next16 & ~15u) + 16u * kRingPieces;         // offset of the next piece to ask for
     constexpr uint32_t kNoPiece = 0xFFFFFFFFu;
     uint32_t quad_at = kNoPiece;                                 // the piece in flight (asked for at the previous phase)
     Quad quad;
     quad.w[0] = quad.w[1] = quad.w[2] = quad.w[3] = 0;
+    // piece `at` (a multiple of 16) = dwords 4p .. 4p+3 of the ring, p = (at / 16) mod 4: two ds_write2_b32
+#define GPUAR_RING_PUT(AT, Q)                                                                                        \
+    {                                                                                                                \
+        uint32_t *slot = reinterpret_cast<uint32_t *>(ring + (((AT) & 0x30u) << 6));                                 \
+        slot[0] = (Q).w[0], slot[64] = (Q).w[1], slot[128] = (Q).w[2], slot[192] = (Q).w[3];                         \
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kRingPieces; ++k) {
         const uint32_t at = (next16 & ~15u) + 16u * k;
         const Quad q = load128(base16 + (at < last_piece ? at : last_piece));
-        store128(ring + ((at & 0x30u) << 6), q.w[0], q.w[1], q.w[2], q.w[3]);
+        GPUAR_RING_PUT(at, q)
     }
 #define GPUAR_RING_PHASE                                                                                             \
     {                                                                                                                \
-        if (quad_at != kNoPiece) store128(ring + ((quad_at & 0x30u) << 6), quad.w[0], quad.w[1], quad.w[2], quad.w[3]); \
-        if (fill - next16 <= 48u) {                                                                                  \
+        if (quad_at != kNoPiece) GPUAR_RING_PUT(quad_at, quad)                                                       \
+        if (fill - (next64 >> 6) <= 48u) {                                                                           \
             quad = load128(base16 + (fill < last_piece ? fill : last_piece));                                        \
             quad_at = fill;                                                                                          \
             fill += 16u;                                                                                             \
@@ -725,9 +733,10 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
 #undef GPUAR_SHIFT_OF
 #undef GPUAR_ROTATE_RECIPS
 #undef GPUAR_RING_PHASE
+#undef GPUAR_RING_PUT
     // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dec.ahead) : : "memory");
-    dec.next = next16 - skew16;
+    dec.next = (next64 >> 6) - skew16;
     dec.off = offr;
     dec.owed_bits = nbits;
     dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
@@ -750,12 +759,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, const uint8_t *base, u
 
 __global__ void __launch_bounds__(kLanes)
 decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint4 lds[kDecodeLdsQuads];             // 40 KiB: (36 records + 4 ring pieces) x 64 lanes x 16 B
+    __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];    // 40 KiB: 36 records x 64 lanes x 16 B, then 4 KiB of stream rings
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const uint8_t *group_slots = slots + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);      // wave-uniform
-    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), group_slots, lane * kSlot, (lane + 1u) * kSlot,
+    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, (lane + 1u) * kSlot,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
@@ -764,7 +773,7 @@ decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8
 __global__ void __launch_bounds__(kLanes)
 decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offsets,
                      uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ uint4 lds[kDecodeLdsQuads];
+    __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
@@ -776,7 +785,7 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint64_t left = offsets[n_packets] - first;                       // bytes from the base to the end of the stream
     const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
     const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
-    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), group_stream, pkt_off, limit_off,
+    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_stream, pkt_off, limit_off,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
