@@ -666,10 +666,11 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         recip_next = g_recip.r[ahead_at < kPacket ? ahead_at : kPacket - 1u];                                        \
     }
 #define GPUAR_MUL_OF(J) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(J)))
-#define GPUAR_SHIFT_OF(J) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.shift), static_cast<int>(J)))
+#define GPUAR_SHIFT_OF(J) block_shift   /* the same for all 64 symbols of a block, see RecipTable */
 #define GPUAR_DECODE_BLOCK(SYMBOL)                                                                                   \
     {                                                                                                                \
         uint32_t block[16];                                                                                          \
+        const uint32_t block_shift = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.shift), 0)); \
         _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 2u) {                                                 \
             const uint32_t j0 = 4u * g; /* wave-uniform: first symbol of this run inside the block */               \
             const uint32_t total0 = 256u + i + j0;                                                                   \

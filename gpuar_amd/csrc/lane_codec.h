@@ -69,8 +69,8 @@ constexpr uint32_t kDecodeRecords = 36;            // 16-byte subtree records of
 
 // ---------------------------------------------------------------------------
 // Exact division by the wave-uniform model total d = 256 + i, i in [0, 8192).
-// For n < 2^30 and 2^(l-1) < d <= 2^l:  floor(n/d) == (n * m) >> (30 + l)
-// with m = ceil(2^(30+l) / d) < 2^31  (Granlund & Montgomery, N = 30).
+// For n < 2^30 and 2^(l-1) <= d < 2^l:  floor(n/d) == (n * m) >> (30 + l)
+// with m = ceil(2^(30+l) / d) <= 2^31  (Granlund & Montgomery, N = 30: exact because m * d - 2^(30+l) < d <= 2^l).
 // Numerators here are cum * range <= d * 65536 < 2^30 because the model total
 // never exceeds 256 + 8192 < 2^14 (the guard of src/compressor.cpp:13-16).
 // ---------------------------------------------------------------------------
@@ -85,7 +85,8 @@ struct RecipTable {
         for (uint32_t i = 0; i < kPacket; ++i) {
             const uint64_t d = 256u + i;
             uint32_t l = 8;
-            while ((1ull << l) < d) ++l;
+            while ((1ull << l) <= d) ++l;   // 2^(l-1) <= d < 2^l: a power of two takes the shift of the totals after it,
+                                            // so the shift is the same for all 64 symbols of a block (d = 256 + i, i = 64 b + j)
             const uint64_t m = ((1ull << (30 + l)) + d - 1) / d;
             r[i].mul = static_cast<uint32_t>(m);
             r[i].shift = l - 2;  // (n*m) >> (30+l) == hi32(n*m) >> (l-2)
