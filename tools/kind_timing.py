@@ -16,12 +16,15 @@ def main():
     ap.add_argument("--gib", type=float, default=2.0)
     ap.add_argument("--kinds", default="uniform,text,zipf,zeros")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--slot", type=int, default=None, help="slot stride the experiment build was compiled with (-DGPUAR_SLOT_BYTES=...)")
     ap.add_argument("--lib", default=None, help="an experiment build of libgpuar_hip.so to time instead of the product one")
     a = ap.parse_args()
     import torch
     from gpuar_amd import hip as H
     if a.lib:
         H.LIB_PATH = os.path.abspath(a.lib)
+    if a.slot:
+        H.SLOT = a.slot
     n = int(a.gib * (1 << 30)) // 8192 * 8192
     npk = H.packet_count(n)
     d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device="cuda")

@@ -16,12 +16,15 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kind", default="uniform")
     ap.add_argument("--only", default="both", choices=["both", "encode", "decode"])
+    ap.add_argument("--slot", type=int, default=None, help="slot stride of an experiment build (-DGPUAR_SLOT_BYTES=...)")
     ap.add_argument("--lib", default=None, help="an experiment build of libgpuar_hip.so to profile instead of the product one")
     a = ap.parse_args()
     import torch
     from gpuar_amd import hip as H
     if a.lib:
         H.LIB_PATH = os.path.abspath(a.lib)
+    if a.slot:
+        H.SLOT = a.slot
     n = int(a.gib * (1 << 30)) // 8192 * 8192
     d_in = H.generate(a.kind, 42, n)
     npk = H.packet_count(n)
