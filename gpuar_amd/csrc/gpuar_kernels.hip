@@ -618,32 +618,49 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     uint32_t next64 = next16 << 6;                               // ... carried times 64: bits 8-11 = 256 * (dword index mod 16)
     const uint32_t last_piece = (dec.last + skew16) & ~15u;
     uint32_t fill = (next16 & ~15u) + 16u * kRingPieces;         // offset of the next piece to ask for
-    constexpr uint32_t kNoPiece = 0xFFFFFFFFu;
-    uint32_t quad_at = kNoPiece;                                 // the piece in flight (asked for at the previous phase)
-    Quad quad;
-    quad.w[0] = quad.w[1] = quad.w[2] = quad.w[3] = 0;
-    // piece `at` (a multiple of 16) = dwords 4p .. 4p+3 of the ring, p = (at / 16) mod 4: two ds_write2_b32
-#define GPUAR_RING_PUT(AT, Q)                                                                                        \
-    {                                                                                                                \
-        uint32_t *slot = reinterpret_cast<uint32_t *>(ring + (((AT) & 0x30u) << 6));                                 \
-        slot[0] = (Q).w[0], slot[64] = (Q).w[1], slot[128] = (Q).w[2], slot[192] = (Q).w[3];                         \
-    }
+    // piece `at` (a multiple of 16) = dwords 4p .. 4p+3 of the ring, p = (at / 16) mod 4: two ds_write2st64_b32
+    register uint32_t q0 asm("v220");          // the piece asked for last (in flight, or already in the ring:
+    register uint32_t q1 asm("v221");          // writing it a second time is harmless) ...
+    register uint32_t q2 asm("v222");
+    register uint32_t q3 asm("v223");
+    uint32_t slot_lds = ring_lds;              // ... and the LDS address of its dword 0
 #pragma unroll
     for (uint32_t k = 0; k < kRingPieces; ++k) {
         const uint32_t at = (next16 & ~15u) + 16u * k;
         const Quad q = load128(base16 + (at < last_piece ? at : last_piece));
-        GPUAR_RING_PUT(at, q)
+        uint32_t *slot = reinterpret_cast<uint32_t *>(ring + ((at & 0x30u) << 6));
+        slot[0] = q.w[0], slot[64] = q.w[1], slot[128] = q.w[2], slot[192] = q.w[3];
+        if (k == kRingPieces - 1u) {
+            q0 = q.w[0], q1 = q.w[1], q2 = q.w[2], q3 = q.w[3];
+            slot_lds = ring_lds + ((at & 0x30u) << 6);
+        }
     }
+    // One phase, by hand (the compiler's version of it, two divergent branches and their bookkeeping, was 24 issue
+    // slots per four symbols): the piece asked for last is (re)written to its place, then the lanes whose reader
+    // is within 48 bytes of `fill` ask for the next piece -- a predicated region without a branch around it.
+    // s_waitcnt vmcnt(0): the piece was asked for a phase ago; the block's output stores drain here as well.
 #define GPUAR_RING_PHASE                                                                                             \
     {                                                                                                                \
-        if (quad_at != kNoPiece) GPUAR_RING_PUT(quad_at, quad)                                                       \
-        if (fill - (next64 >> 6) <= 48u) {                                                                           \
-            quad = load128(base16 + (fill < last_piece ? fill : last_piece));                                        \
-            quad_at = fill;                                                                                          \
-            fill += 16u;                                                                                             \
-        } else {                                                                                                     \
-            quad_at = kNoPiece;                                                                                      \
-        }                                                                                                            \
+        uint32_t t_, t2_;                                                                                            \
+        unsigned long long sx_;                                                                                      \
+        asm volatile(                                                                                                \
+            "s_waitcnt vmcnt(0)\n\t"                                                                                 \
+            "ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                                    \
+            "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t"                                          \
+            "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
+            "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
+            "v_cmp_gt_u32 vcc, 49, %[t]\n\t"                                                                         \
+            "s_and_saveexec_b64 %[sx], vcc\n\t"                                                                      \
+            "v_min_u32 %[t], %[fill], %[lastp]\n\t"                                                                  \
+            "global_load_dwordx4 v[220:223], %[t], %[base]\n\t"                                                      \
+            "v_and_b32 %[t2], 48, %[fill]\n\t"                                                                       \
+            "v_lshl_add_u32 %[slot], %[t2], 6, %[ring]\n\t"                                                          \
+            "v_add_u32 %[fill], 16, %[fill]\n\t"                                                                     \
+            "s_or_b64 exec, exec, %[sx]"                                                                             \
+            : [slot] "+v"(slot_lds), [fill] "+v"(fill), [t] "=&v"(t_), [t2] "=&v"(t2_), [sx] "=&s"(sx_),             \
+              "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)                                                                 \
+            : [next] "v"(next64), [lastp] "v"(last_piece), [base] "s"(base16), [ring] "v"(ring_lds)                  \
+            : "vcc", "memory");                                                                                      \
     }
 
     // The per-symbol reciprocals (Recip: 8 bytes per symbol, wave-uniform) reach the symbol step WITHOUT scalar
@@ -734,9 +751,9 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 #undef GPUAR_SHIFT_OF
 #undef GPUAR_ROTATE_RECIPS
 #undef GPUAR_RING_PHASE
-#undef GPUAR_RING_PUT
     // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dec.ahead) : : "memory");
+    // (and a piece the last ring phase asked for may still be on its way into v220-v223)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(dec.ahead), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
     dec.next = (next64 >> 6) - skew16;
     dec.off = offr;
     dec.owed_bits = nbits;
