@@ -682,7 +682,9 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         const uint32_t ahead_at = i + 64u + lane_id;                                                                 \
         recip_next = g_recip.r[ahead_at < kPacket ? ahead_at : kPacket - 1u];                                        \
     }
-#define GPUAR_MUL_OF(J) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(J)))
+// The lane select of v_readlane_b32 is the low six bits of its scalar operand, and the model total of symbol
+// i + j is 256 + i + j with i a multiple of 64: the total itself selects lane j (no separate index to count up).
+#define GPUAR_MUL_OF(TOTAL) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(TOTAL)))
 #define GPUAR_SHIFT_OF(J) block_shift   /* the same for all 64 symbols of a block, see RecipTable */
 #define GPUAR_DECODE_BLOCK(SYMBOL)                                                                                   \
     {                                                                                                                \
@@ -692,16 +694,16 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             const uint32_t j0 = 4u * g; /* wave-uniform: first symbol of this run inside the block */               \
             const uint32_t total0 = 256u + i + j0;                                                                   \
             uint32_t word, np_out;                                                                                   \
-            SYMBOL(total0, GPUAR_MUL_OF(j0), GPUAR_SHIFT_OF(j0), np_out) word = np_out;                              \
-            SYMBOL(total0 + 1u, GPUAR_MUL_OF(j0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), np_out) word |= np_out << 8;         \
-            SYMBOL(total0 + 2u, GPUAR_MUL_OF(j0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), np_out) word |= np_out << 16;        \
-            SYMBOL(total0 + 3u, GPUAR_MUL_OF(j0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), np_out) word |= np_out << 24;        \
+            SYMBOL(total0, GPUAR_MUL_OF(total0), GPUAR_SHIFT_OF(j0), np_out) word = np_out;                              \
+            SYMBOL(total0 + 1u, GPUAR_MUL_OF(total0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), np_out) word |= np_out << 8;         \
+            SYMBOL(total0 + 2u, GPUAR_MUL_OF(total0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), np_out) word |= np_out << 16;        \
+            SYMBOL(total0 + 3u, GPUAR_MUL_OF(total0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), np_out) word |= np_out << 24;        \
             block[g] = ~word; /* np holds the COMPLEMENTED symbol bits */                                            \
             GPUAR_RING_PHASE                                                                                         \
-            SYMBOL(total0 + 4u, GPUAR_MUL_OF(j0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), np_out) word = np_out;               \
-            SYMBOL(total0 + 5u, GPUAR_MUL_OF(j0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), np_out) word |= np_out << 8;         \
-            SYMBOL(total0 + 6u, GPUAR_MUL_OF(j0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), np_out) word |= np_out << 16;        \
-            SYMBOL(total0 + 7u, GPUAR_MUL_OF(j0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), np_out) word |= np_out << 24;        \
+            SYMBOL(total0 + 4u, GPUAR_MUL_OF(total0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), np_out) word = np_out;               \
+            SYMBOL(total0 + 5u, GPUAR_MUL_OF(total0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), np_out) word |= np_out << 8;         \
+            SYMBOL(total0 + 6u, GPUAR_MUL_OF(total0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), np_out) word |= np_out << 16;        \
+            SYMBOL(total0 + 7u, GPUAR_MUL_OF(total0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), np_out) word |= np_out << 24;        \
             block[g + 1u] = ~word;                                                                                   \
             GPUAR_RING_PHASE                                                                                         \
         }                                                                                                            \
