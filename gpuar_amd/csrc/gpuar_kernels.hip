@@ -387,7 +387,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
             "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
 
-#define GPUAR_BC_TEXT \
+#define GPUAR_BC_MID \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: w0 = a | bR << 16, w1 = - | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
             "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
@@ -418,8 +418,10 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 v210, %[cc], v202, %[ma]\n\t" \
             "v_cndmask_b32 v211, v203, %[cc], %[ma]\n\t" \
             "v_addc_co_u32 v208, %[mj], v208, 0, %[ma]\n\t" \
-            "ds_write_b128 %[am], v[208:211]\n\t" \
-            "s_waitcnt lgkmcnt(1)\n\t" \
+            "ds_write_b128 %[am], v[208:211]\n\t"
+
+#define GPUAR_BC_LOW \
+            "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid record's write-back, perhaps the stream reader's dword) */ \
          /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16. \
                  Z = R - V with V = scaled distance from the walk's origin to the upper end of the subtree it is in: \
                  S * range on entry; going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
@@ -529,7 +531,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
         GPUAR_STEP_LOCALS \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_STREAM_TEXT GPUAR_BC_TEXT GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "+s"(lma), [lmc] "+s"(lmc), \
               "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) \
@@ -544,7 +546,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         GPUAR_STEP_LOCALS \
         uint32_t lbw_, lcc_; \
         unsigned long long lma_, lmc_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_STREAM_TEXT GPUAR_BC_TEXT GPUAR_OFF_TEXT GPUAR_BC_TAIL_PLAIN \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_PLAIN \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
               "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) \
@@ -578,6 +580,10 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // ---- state of the hand-scheduled step ----
     const uint32_t col_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(col));   // LDS byte address of this lane's column
     const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));  // ... and of dword 0 of its stream ring
+    // the refill's address arithmetic ORs a dword index into bits 8-11: the ring region must start on a 4 KiB
+    // boundary of LDS (the kernels' only __shared__ array is declared that way); anything else is a build error
+    // that would decode garbage, so it stops the kernel instead
+    if ((ring_lds & 0xF00u) != 0u) __builtin_trap();
     register uint32_t o0 asm("v204");          // PLAIN: low record of the previous symbol, rebuilt, not yet written back
     register uint32_t o1 asm("v205");
     register uint32_t o2 asm("v206");
