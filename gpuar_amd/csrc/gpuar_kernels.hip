@@ -11,7 +11,8 @@
 //    lane-minor so lane l always hits bank l & 31; software-pipelined walks
 //    over depths 1-6 and {0, 7} that yield cumLo, cumHi and the count update)
 //    and a CODER (interval narrowing by a wave-uniform reciprocal, closed-form
-//    renormalisation, bit sink), joined by an LDS ring; a fourth, idle
+//    renormalisation, bit sink), one phase apart from each other and handing a
+//    phase on in place through a three-slot LDS ring; a fourth, idle
 //    wavefront makes the workgroup cover all four SIMDs so that roles can be
 //    dealt out per SIMD;
 //  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
@@ -62,15 +63,17 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // Workgroup = 4 wavefronts, three of them working on the same 64 packets (lane l
 // <-> packet 64*group + l in all three); which wavefront plays which role is
 // decided per SIMD at run time (see encode_kernel):
-//   TOP MODELER: depths 1..6 of the 64 adaptive models (LDS), reads the input
-//           bytes, emits its part of cumLo | cumHi << 16 per symbol;
-//   LOW MODELER: depth 0 (a register), depth 7 (LDS) and the x == 255 term, same
-//           input, emits the other part (why 6 + 1: lane_codec.h at TopModeler);
-//   CODER: adds the two parts, owns the interval state and the bit sink, turns
-//           them into the packet bitstream;
+//   TOP MODELER: reads the input bytes from memory (whole 128-byte lines), walks
+//           depths 1..6 of the 64 adaptive models (LDS), emits its part of
+//           cumLo | cumHi << 16 per symbol and hands the bytes on;
+//   LOW MODELER: one phase behind: depth 0 (a register), depth 7 (LDS) and the
+//           x == 255 term, added onto the top modeler's part in place (why 6 + 1:
+//           lane_codec.h at TopModeler);
+//   CODER: two phases behind: owns the interval state and the bit sink, turns the
+//           sums into the packet bitstream;
 //   the fourth wavefront only meets the barriers.
-// They meet in a two-half LDS ring of kPhase symbols per half: the modelers
-// fill half (k & 1) while the coder drains the other, one s_barrier per phase.
+// They meet in a three-slot LDS ring of kPhase symbols per slot (EncodeLds), one
+// s_barrier per phase.
 //
 // Why three: a packet's model pins 510 B of LDS, so a CU holds only 4 x 64
 // packets however the work is arranged, and a lone wavefront issues at most
@@ -79,7 +82,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // ran at 108 GB/s; modeler + coder at 290 GB/s with the modeler's serial
 // stream (45 VALU + 13 LDS per symbol) as the bottleneck; cutting that stream
 // in two puts three wavefronts on every SIMD for the same LDS.  32 KiB tree +
-// 8 KiB ring = 40 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
+// 8 KiB of rings = 40 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
 // (plus the 4 idle ones that only meet the barriers, see encode_kernel).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPhase = 8;
@@ -90,10 +93,19 @@ constexpr uint32_t kPhase = 8;
 // roles swapped -- whoever walks four LDS levels has to go first, the three-level modeler last.
 constexpr int kPrioTop = 3, kPrioCoder = 1, kPrioLow = 0;
 
+// The three roles work one phase apart -- the top modeler on the symbols of phase p, the low modeler on those of
+// p - 1, the coder on those of p - 2 -- and hand a phase on IN PLACE: the top modeler writes its part of
+// cumLo | cumHi << 16 per symbol, the low modeler adds its own, the coder reads the sum.  Three phases are alive at
+// a time, so the ring has three slots.  The low modeler takes the input bytes from the top one as well (two dwords
+// per lane and phase), so only one wavefront of a group reads the input from memory.
+constexpr uint32_t kRingSlots = 3;
 struct EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
-    uint32_t ring[2][kPhase][2][kLanes];       // 8 KiB: [half][symbol][part][lane], parts add up to cumLo | cumHi << 16
+    uint32_t sums[kRingSlots][kPhase][kLanes]; // 6 KiB: [slot][symbol][lane]
+    uint32_t bytes[2][2][kLanes];              // 1 KiB: [phase parity][dword][lane], the eight input bytes of a phase
+    uint32_t spare[256];                       // 1 KiB (the role hand-shake at the start uses it)
 };
+__device__ __forceinline__ uint32_t next_slot(uint32_t slot) { return slot == kRingSlots - 1u ? 0u : slot + 1u; }
 
 // Which group of 64 packets a workgroup serves.  Workgroups are dealt to the eight XCDs round-robin
 // (blockIdx & 7), each XCD with its own L2.  Serving groups in blockIdx order would give one XCD every
@@ -120,22 +132,21 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One modeler wavefront: `Model` is TopModeler<7> (part 0) or LowModeler<7> (part 1).
+// The top modeler's wavefront.
 //
-// Input fetch: 64 bytes per lane (four back-to-back 16-byte loads of the same 128-byte line) once
-// per CHUNK of eight phases, issued a whole chunk ahead of use.  Lanes sit 8192 bytes apart, so the
-// lines all the packets of an XCD are reading at one moment fall into the same few L2 sets and do
-// not survive until the lane comes back for the next piece: every touch of a line is a fetch from
-// memory (rocprofv3 FETCH_SIZE showed 3.3x the input with 16-byte pieces, two modelers each).
-// Fewer, larger touches are the cure that costs no LDS.
-template <typename Model, uint32_t kPart>
-__device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, uint32_t lane, uint32_t len,
-                                            uint32_t len_min, uint32_t n_phases) {
+// Input fetch: 64 bytes per lane and CHUNK of eight phases, issued at least a chunk ahead of use, as
+// back-to-back 16-byte loads.  Lanes sit 8192 bytes apart, so the lines all the packets of an XCD are
+// reading at one moment fall into the same few L2 sets and do not survive until the lane comes back:
+// every touch of a line is a fetch from memory (rocprofv3 FETCH_SIZE: 3.3x the input with 16-byte
+// pieces and two modelers reading, 1.2-1.8x with 64-byte pieces, 1.01x now that one wavefront reads
+// and takes the whole 128-byte line at a time).
+__device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint32_t lane, uint32_t len,
+                                        uint32_t len_min, uint32_t n_phases) {
     constexpr uint32_t kChunkPhases = 8;                       // phases per fetch
     constexpr uint32_t kChunk = kChunkPhases * kPhase;         // 64 symbols = 64 bytes = 4 x 16-byte loads
     constexpr uint32_t kPieces = kChunk / 16u;
-    Model model;
-    uint32_t k = 0;
+    TopModeler<7> model;
+    uint32_t k = 0, slot = 0;
     {
         const uint32_t first = len ? load16_guarded(in, len).x & 0xFFu : 0u;
         model.open(lds.tree, 2u * lane_column(lane), first);
@@ -144,17 +155,27 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
     const uint32_t full_chunks = len_min / kChunk;
     if (full_chunks) {
         const uint4 *src = reinterpret_cast<const uint4 *>(in);
-        uint4 c[kPieces];
-#pragma unroll
-        for (uint32_t t = 0; t < kPieces; ++t) c[t] = src[t];
-        for (uint32_t q = 0; q < full_chunks; ++q) {
-            uint4 n[kPieces];                                 // the chunk after this one (don't-care past the packet)
+        // A 128-byte line of the input holds two chunks.  Both halves are asked for together (at the start of every
+        // odd chunk, for the two chunks behind it) so that a line is fetched from memory once: with one half per
+        // chunk the line was gone from L2 by the time the lane came back for the other (8192 packets 8 KiB apart).
+        auto fetch = [&](uint32_t chunk, uint4 (&into)[kPieces]) {
 #pragma unroll
             for (uint32_t t = 0; t < kPieces; ++t) {
-                const uint32_t at = (q + 1u) * kChunk + 16u * t;
-                if (at + 16u <= len) n[t] = src[kPieces * (q + 1u) + t];
-                else if (at < len) n[t] = load16_guarded(in + at, len - at);
-                else n[t] = make_uint4(0, 0, 0, 0);
+                const uint32_t at = chunk * kChunk + 16u * t;
+                if (at + 16u <= len) into[t] = src[kPieces * chunk + t];
+                else if (at < len) into[t] = load16_guarded(in + at, len - at);
+                else into[t] = make_uint4(0, 0, 0, 0);
+            }
+        };
+        uint4 c[kPieces], n[kPieces], nn[kPieces];            // this chunk, the next one, the one after (odd chunks only)
+        fetch(0, c);
+        fetch(1, n);
+#pragma unroll
+        for (uint32_t t = 0; t < kPieces; ++t) nn[t] = make_uint4(0, 0, 0, 0);
+        for (uint32_t q = 0; q < full_chunks; ++q) {
+            if (q & 1u) {                                     // wave-uniform
+                fetch(q + 1u, n);
+                fetch(q + 2u, nn);
             }
             uint32_t w[kChunk / 4u + 1u];
 #pragma unroll
@@ -162,26 +183,30 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
             w[kChunk / 4u] = n[0].x;
 #pragma unroll
             for (uint32_t ph = 0; ph < kChunkPhases; ++ph) {
-                uint32_t *out = &lds.ring[ph & 1u][0][kPart][lane];      // k = kChunkPhases * q + ph, first term even
+                uint32_t *out = &lds.sums[slot][0][lane];
+                lds.bytes[ph & 1u][0][lane] = w[2u * ph];                // k = kChunkPhases * q + ph, first term even
+                lds.bytes[ph & 1u][1][lane] = w[2u * ph + 1u];
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {
                     const uint32_t i = ph * kPhase + j;                  // symbol index inside the chunk
                     const uint32_t x = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
                     const uint32_t x_next = (w[(i + 1) >> 2] >> (8u * ((i + 1) & 3u))) & 0xFFu;
-                    out[j * 2u * kLanes] = model.step(x, 256u + q * kChunk + i, x_next);
+                    out[j * kLanes] = model.step(x, 256u + q * kChunk + i, x_next);
                 }
+                slot = next_slot(slot);
                 lds_barrier();
             }
 #pragma unroll
-            for (uint32_t t = 0; t < kPieces; ++t) c[t] = n[t];
+            for (uint32_t t = 0; t < kPieces; ++t) c[t] = n[t], n[t] = nn[t];
         }
         k = kChunkPhases * full_chunks;
     }
-    // ---- the rest: the phases that hold the file's ragged tail (or a partly dead wavefront) ----
+    // ---- the rest: the phases that hold the file's ragged tail (or a partly dead wavefront), then two phases
+    //      in which the other roles finish ----
     uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
     if (k * kPhase < len) cur = load16_guarded(in + k * kPhase, len - k * kPhase);
     if (k * kPhase + 16u < len) nxt = load16_guarded(in + k * kPhase + 16u, len - (k * kPhase + 16u));
-    for (; k <= n_phases; ++k) {
+    for (; k < n_phases + 2u; ++k) {
         if (k < n_phases) {
             const uint32_t base = k * kPhase;
             const bool odd = (k & 1u) != 0u;                   // wave-uniform: second half of `cur`
@@ -190,8 +215,11 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
                 cur = nxt;
                 const uint32_t ahead = base + kPhase + 16u;
                 if (ahead < len) nxt = load16_guarded(in + ahead, len - ahead);
+                else nxt = make_uint4(0, 0, 0, 0);
             }
-            uint32_t *out = &lds.ring[k & 1u][0][kPart][lane];
+            uint32_t *out = &lds.sums[slot][0][lane];
+            lds.bytes[k & 1u][0][lane] = words[0];
+            lds.bytes[k & 1u][1][lane] = words[1];
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q) {
                 uint32_t w = words[q], w_next = words[q + 1];
@@ -202,12 +230,58 @@ __device__ __forceinline__ void run_modeler(EncodeLds &lds, const uint8_t *in, u
                     w = (w >> 8) | (w_next << 24);            // next symbol now in the low byte
                     w_next >>= 8;
                     if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
-                    out += 2u * kLanes;
+                    out += kLanes;
                 }
             }
+            slot = next_slot(slot);
         }
         lds_barrier();
     }
+}
+
+// The low modeler: one phase behind the top one; input bytes and the top modeler's parts come through LDS, the
+// sums go back to the same slot.  The last symbol of a phase does not know its successor yet (the top modeler is
+// writing it in this very phase), so the node of a phase's first symbol is fetched when the phase begins.
+__device__ __forceinline__ void run_low(EncodeLds &lds, uint32_t lane, uint32_t len, uint32_t len_min, uint32_t n_phases) {
+    LowModeler<7> model;
+    model.open(lds.tree, 2u * lane_column(lane), 0u);          // (the prefetch for symbol 0 is repeated below: harmless)
+    lds_barrier();                                             // phase 0: the top modeler's first
+    uint32_t slot = 0;
+    for (uint32_t k = 0; k < n_phases; ++k) {                  // the symbols of phase k, during phase k + 1
+        const uint32_t base = k * kPhase;
+        uint32_t *io = &lds.sums[slot][0][lane];
+        const uint32_t w0 = lds.bytes[k & 1u][0][lane], w1 = lds.bytes[k & 1u][1][lane];
+        if (base + kPhase <= len_min) {
+            uint32_t part[kPhase];
+#pragma unroll
+            for (uint32_t j = 0; j < kPhase; ++j) part[j] = io[j * kLanes];
+            model.prime(w0 & 0xFFu);
+#pragma unroll
+            for (uint32_t j = 0; j < kPhase; ++j) {
+                const uint32_t w = j < 4u ? w0 : w1;
+                const uint32_t x = (w >> (8u * (j & 3u))) & 0xFFu;
+                if (j + 1u < kPhase) {
+                    const uint32_t wn = j + 1u < 4u ? w0 : w1;
+                    io[j * kLanes] = model.step(x, 256u + base + j, (wn >> (8u * ((j + 1u) & 3u))) & 0xFFu, part[j]);
+                } else {
+                    io[j * kLanes] = model.step_last(x, 256u + base + j, part[j]);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t j = 0; j < kPhase; ++j) {
+                const uint32_t i = base + j;
+                const uint32_t x = ((j < 4u ? w0 : w1) >> (8u * (j & 3u))) & 0xFFu;
+                if (i < len) {
+                    model.prime(x);
+                    io[j * kLanes] = model.step_last(x, 256u + i, io[j * kLanes]);
+                }
+            }
+        }
+        slot = next_slot(slot);
+        lds_barrier();
+    }
+    lds_barrier();                                             // phase n_phases + 1: the coder's last
 }
 
 __global__ void __launch_bounds__(4 * kLanes)
@@ -228,7 +302,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_ID
     const uint32_t simd = (hw >> 4) & 3u;
-    uint32_t *hello = &lds.ring[0][0][0][0];                 // ring space, not in use yet
+    uint32_t *hello = &lds.spare[0];
     if (lane == 0) hello[wave] = simd;
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID
@@ -248,14 +322,16 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint32_t n_phases = (len_max + kPhase - 1) / kPhase;
     const uint8_t *in = src + (live ? start : 0);
 
+    // every role meets n_phases + 2 barriers: the top modeler works in phases 0 .. n_phases - 1, the low one in
+    // 1 .. n_phases, the coder in 2 .. n_phases + 1
     if (role == 0) {
         __builtin_amdgcn_s_setprio(kPrioTop);
-        run_modeler<TopModeler<7>, 0>(lds, in, lane, len, len_min, n_phases);
+        run_top(lds, in, lane, len, len_min, n_phases);
     } else if (role == 1) {
         __builtin_amdgcn_s_setprio(kPrioLow);
-        run_modeler<LowModeler<7>, 1>(lds, in, lane, len, len_min, n_phases);
+        run_low(lds, lane, len, len_min, n_phases);
     } else if (role == 3) {
-        for (uint32_t k = 0; k <= n_phases; ++k) lds_barrier();
+        for (uint32_t k = 0; k < n_phases + 2u; ++k) lds_barrier();
     } else {
         // ------------------------------- coder -------------------------------
         __builtin_amdgcn_s_setprio(kPrioCoder);
@@ -263,36 +339,38 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint8_t *block_slots = dst + group * (kLanes * kSlot);
         CoderLane coder;
         coder.open(block_slots, lane * kSlot);
-            Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
+        Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
 #pragma unroll
         for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[j];
-        for (uint32_t k = 0; k <= n_phases; ++k) {
-            if (k >= 1) {
-                const uint32_t base = (k - 1u) * kPhase;
-                const uint32_t *in_ring = &lds.ring[(k - 1u) & 1u][0][0][lane];
-                if (base + kPhase <= len_min) {
-                    uint32_t cums[kPhase];
+        lds_barrier();                                       // phases 0 and 1: the modelers' first
+        lds_barrier();
+        uint32_t slot = 0;
+        for (uint32_t k = 0; k < n_phases; ++k) {            // the symbols of phase k, during phase k + 2
+            const uint32_t base = k * kPhase;
+            const uint32_t *in_ring = &lds.sums[slot][0][lane];
+            if (base + kPhase <= len_min) {
+                uint32_t cums[kPhase];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in_ring[j * 2u * kLanes] + in_ring[j * 2u * kLanes + kLanes];
-                    Recip rc[kPhase];
+                for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in_ring[j * kLanes];
+                Recip rc[kPhase];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) rc[j] = rc_next[j];
-                    uint32_t ahead = base + kPhase;                      // wave-uniform
-                    ahead = ahead > kPacket - kPhase ? kPacket - kPhase : ahead;
+                for (uint32_t j = 0; j < kPhase; ++j) rc[j] = rc_next[j];
+                uint32_t ahead = base + kPhase;                      // wave-uniform
+                ahead = ahead > kPacket - kPhase ? kPacket - kPhase : ahead;
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[ahead + j];
+                for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[ahead + j];
 #pragma unroll
-                    for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
-                } else {
+                for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
+            } else {
 #pragma unroll 1
-                    for (uint32_t j = 0; j < kPhase; ++j) {
-                        const uint32_t i = base + j;
-                        if (i >= len_max) break;
-                        const Recip r = g_recip.r[i];
-                        if (i < len) coder.step(in_ring[j * 2u * kLanes] + in_ring[j * 2u * kLanes + kLanes], r);
-                    }
+                for (uint32_t j = 0; j < kPhase; ++j) {
+                    const uint32_t i = base + j;
+                    if (i >= len_max) break;
+                    const Recip r = g_recip.r[i];
+                    if (i < len) coder.step(in_ring[j * kLanes], r);
                 }
             }
+            slot = next_slot(slot);
             lds_barrier();
         }
         if (live) {

@@ -228,7 +228,12 @@ struct PartialModeler {
         }
         root = 128u;
         half0 = half1 = 64u;
-        const uint32_t xs = tree.tag(first_symbol);
+        prime(first_symbol);
+    }
+
+    // fetch this part's nodes of symbol x, the next one to account (what step() does for its x_next)
+    GPUAR_LANE void prime(uint32_t x) {
+        const uint32_t xs = tree.tag(x);
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
             where[k] = tree.node(xs, kFirst + k);
@@ -236,11 +241,33 @@ struct PartialModeler {
         }
     }
 
-    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next) {
+    // step() for a symbol whose successor is not known yet: nothing is fetched ahead, prime() has to follow
+    GPUAR_LANE uint32_t step_last(uint32_t x, uint32_t total, uint32_t onto = 0) {
+        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;
+        uint32_t acc = onto;
+        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);
+        if (kHead >= 1) {
+            const uint32_t pick0 = (z >> 7) & 0x10001u;
+            acc = GPUAR_MAD24(root, pick0, acc);
+            root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
+        }
+        static_assert(kHead < 2, "step_last: depth 1 in registers is not carried here");
+#pragma unroll
+        for (int k = 0; k < kDepths; ++k) {
+            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
+            const uint32_t l = left[k];
+            acc = GPUAR_MAD24(l, pick, acc);
+            *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));
+        }
+        return acc;
+    }
+
+    // `onto`: what the sums are added to (the other modeler's part, when this one runs behind it)
+    GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next, uint32_t onto = 0) {
         const uint32_t xn = tree.tag(x_next);
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
-        uint32_t acc = 0;
-        if (kTail) acc = GPUAR_MUL24((z >> 8) & 0x10001u, total);  // x == 255: cumHi is the whole total
+        uint32_t acc = onto;
+        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);  // x == 255: cumHi is the whole total
         if (kHead >= 1) {
             const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
