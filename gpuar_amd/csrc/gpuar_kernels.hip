@@ -16,7 +16,8 @@
 //    wavefront makes the workgroup cover all four SIMDs so that roles can be
 //    dealt out per SIMD;
 //  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
-//    two 16-byte subtree records per symbol instead of walking eight levels and
+//    two 16-byte subtree records per symbol instead of walking eight levels, writes
+//    back the 8-byte half of each that the path went through, and
 //    works on a scaled remainder (no division, borrow = path bit); the symbol step
 //    is a hand-scheduled instruction stream; the packet stream reaches it through a
 //    per-lane ring in LDS, the per-symbol constants through v_readlane;
@@ -398,19 +399,20 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // vector load the whole wavefront waits for (~720 cycles under load, longer than the step) -- the
 // loop below contains neither.  The compiler's own schedule of lane_codec.h's
 // step_symbol spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane
-// mask it writes); the statement below spends ~112 vector + 5 LDS.
+// mask it writes); the statement below spends ~98 vector + 5 LDS.
 //
 //   R0 = off*total + total - 1; depths 0 and 1 (registers); READ #1 (mid record) issued
-//       in its shadow: the previous symbol's low record rebuilt and written back, register nodes bumped,
-//       the stream window steps over the previous symbol's bits (refill from the LDS ring), peek
+//       in its shadow: the half of the previous symbol's low record that its path took, updated and written
+//       back; register nodes bumped
 //   wait; mid record: 3 decisions; READ #2 (low record) issued
-//       in its shadow: mid record rebuilt and written back
-//   wait; low record: 3 decisions, W = cnt*range; interval narrowed and renormalised;
+//       in its shadow: the mid record's half updated and written back; the stream window steps over the
+//       previous symbol's bits (refill from the LDS ring), peek
+//   wait; low record: 3 decisions, Z for the upper bound; interval narrowed and renormalised;
 //       off = ((off - dn) : window) << n
 //
 // Lane masks: v_sub_co writes "went left" as its borrow; v_min keeps the remainder; the mask is
 // read two or more instructions later (path add-with-carry, selects of the next node and of the
-// record rebuild).  The four 16-byte LDS operands need aligned register quads and the 64-bit shift a
+// record update).  The LDS operands need aligned register quads / pairs and the 64-bit shift a
 // pair: they are pinned (v200-v217); everything else is allocated by the compiler.  Both waits have
 // the form "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" (LDS operations of a
 // wavefront complete in order).  Results are those of DecoderLane::step_symbol (same integers), which
@@ -422,12 +424,12 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
 
 // One symbol of the hand-scheduled decoder (see above), in text pieces.  Two variants are assembled from them:
-//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the low record of a
-//            symbol is rebuilt by the NEXT symbol's step, in the shadow of its first LDS read, from the record as
-//            read (v212-v215) and the path (lane masks lma, lmc and lincb / lx) -- lane masks can only be carried
+//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the low half of a
+//            symbol is updated by the NEXT symbol's step, in the shadow of its first LDS read, from the two dwords
+//            as read (lbw, lcc) and the path (lincb, lx and the lane mask lmc) -- lane masks can only be carried
 //            from one statement to the next in scalar registers where the compiler sees uniform control flow;
 //   PLAIN    for the one wavefront of a file that holds its short last packet (lanes drop out under `if`):
-//            the step rebuilds the record itself into v204-v207.
+//            the step updates the half itself into v204:v205.
 // They use decode_wave's locals by name.
 #define GPUAR_A_HEAD \
             "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
@@ -442,23 +444,18 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 %[np], 0, 2, %[m0]\n\t" \
             "v_addc_co_u32 %[np], vcc, %[np], 0, %[m1]\n\t" /* complemented top two symbol bits */ \
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
-            "ds_read_b128 v[200:203], %[am]\n\t" /* READ #1: mid record */ \
+            "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
 #define GPUAR_A_SHADOW_CARRIED \
-         /* in its shadow: the PREVIOUS symbol's low record (v212-v215 as read, its path in lma / lincb / lx / lmc) is rebuilt and written back */ \
-            "v_add_u32 %[lbw], %[lbw], %[lincb]\n\t" \
+         /* in its shadow: the half of the PREVIOUS symbol's low record its path went through (lbw, lcc as read) gets its \
+            increments (lincb: +1 on the count, +0x10000 on the child if left; lx if lmc: the grandchild) and goes back */ \
+            "v_add_u32 v204, %[lbw], %[lincb]\n\t" \
             "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t" \
-            "v_add_u32 %[lcc], %[lcc], %[lx]\n\t" \
-            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t" \
-            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t" \
-            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t" \
-            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t" \
-            "v_addc_co_u32 v204, vcc, v204, 0, %[lma]\n\t" \
-            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */ \
-            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" \
+            "v_add_u32 v205, %[lcc], %[lx]\n\t" \
+            "ds_write_b64 %[oaddr], v[204:205]\n\t" \
 
 #define GPUAR_A_SHADOW_PLAIN \
-            "ds_write_b128 %[oaddr], v[204:207] offset:4096\n\t" /* the previous symbol's low record, rebuilt by its own step */
+            "ds_write_b64 %[oaddr], v[204:205]\n\t" /* the previous symbol's low half, rebuilt by its own step */
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
@@ -467,57 +464,55 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 
 #define GPUAR_BC_MID \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
-         /* ---- mid record: w0 = a | bR << 16, w1 = - | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16 */ \
-            "v_mul_u32_u24_sdwa %[t0], v200, %[rng]" GPUAR_SDWA_W0 \
+         /* ---- mid record: v200 = aR | bR << 16, v201 = cRR | cRL << 16 (right half), v202 = a | bL << 16, v203 = cLR | cLL << 16 (left half) */ \
+            "v_mul_u32_u24_sdwa %[t0], v202, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_cndmask_b32 %[bw], v200, v201, %[ma]\n\t" /* chosen child in the high half */ \
-            "v_cndmask_b32 %[cc], v202, v203, %[ma]\n\t" /* its two children */ \
+            "v_cndmask_b32 %[bw], v200, v202, %[ma]\n\t" /* the half the path takes: count and chosen child ... */ \
+            "v_cndmask_b32 %[cc], v201, v203, %[ma]\n\t" /* ... and its two children */ \
             "v_mul_u32_u24_sdwa %[t0], %[bw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
+            "v_lshl_add_u32 %[am], %[np], 9, %[col]\n\t" /* where that half lives: its index is the path so far */ \
             "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[mc], %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
-            "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" /* +1 for bL/bR if left at the middle decision */ \
+            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 10, %[col]\n\t" \
-            "ds_read_b128 v[212:215], %[oaddr] offset:4096\n\t" /* READ #2: low record */ \
-         /* ---- mid record rebuilt in the shadow of read #2 */ \
-            "v_add_u32 %[bw], %[bw], %[t3]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
+            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
+         /* ---- the mid half updated and written back in the shadow of read #2 */ \
+            "v_add_u32 v208, %[bw], %[t3]\n\t" \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
-            "v_add_u32 %[cc], %[cc], %[t2]\n\t" \
-            "v_cndmask_b32 v208, %[bw], v200, %[ma]\n\t" \
-            "v_cndmask_b32 v209, v201, %[bw], %[ma]\n\t" \
-            "v_cndmask_b32 v210, %[cc], v202, %[ma]\n\t" \
-            "v_cndmask_b32 v211, v203, %[cc], %[ma]\n\t" \
-            "v_addc_co_u32 v208, %[mj], v208, 0, %[ma]\n\t" \
-            "ds_write_b128 %[am], v[208:211]\n\t"
+            "v_add_u32 v209, %[cc], %[t2]\n\t" \
+            "ds_write_b64 %[am], v[208:209]\n\t"
 
 #define GPUAR_BC_LOW \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid record's write-back, perhaps the stream reader's dword) */ \
-         /* ---- low record: w0 = a | bR << 16, w1 = S | bL << 16, w2 = cRR | cRL << 16, w3 = cLR | cLL << 16. \
+         /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
                  Z = R - V with V = scaled distance from the walk's origin to the upper end of the subtree it is in: \
-                 S * range on entry; going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
+                 S * range on entry (S = a + aR, all eight symbols under the record); going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
                  and >= the old Z since p <= V); going right both R and V lose p and Z stays, while d >= 0: Z' = max_u32(Z, d). \
                  At the leaf cumHi * range = R0 - Z: no width to carry, no select. */ \
-            "v_mul_u32_u24_sdwa %[pa], v212, %[rng]" GPUAR_SDWA_W0 \
-            "v_mul_u32_u24_sdwa %[ps], v213, %[rng]" GPUAR_SDWA_W0 \
+            "v_mul_u32_u24_sdwa %[pa], v214, %[rng]" GPUAR_SDWA_W0 \
+            "v_add_u32_sdwa %[ps], v212, v214 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t" /* S = aR + a */ \
+            "v_mul_u32_u24 %[ps], %[ps], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[lma], %[R], %[pa]\n\t" \
             "v_sub_u32 %[t3], %[R], %[ps]\n\t" /* Z on entry */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
-            "v_cndmask_b32 %[lbw], v212, v213, %[lma]\n\t" \
-            "v_cndmask_b32 %[lcc], v214, v215, %[lma]\n\t" \
+            "v_cndmask_b32 %[lbw], v212, v214, %[lma]\n\t" \
+            "v_cndmask_b32 %[lcc], v213, v215, %[lma]\n\t" \
             "v_mul_u32_u24_sdwa %[pb], %[lbw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[np], 9, %[collow]\n\t" /* the low half that goes back (in the next step's shadow) */ \
             "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[lmc], %[R], %[pc]\n\t" \
@@ -548,23 +543,17 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
 
 #define GPUAR_BC_TAIL_CARRIED \
-         /* ---- what the next step needs to rebuild this low record (it does so in the shadow of its first read) */ \
-            "v_cndmask_b32 %[lincb], 0, %[k64k], vcc\n\t" \
+         /* ---- what the next step needs to update this low half (it does so in the shadow of its first read) */ \
+            "v_cndmask_b32 %[lincb], 1, %[k64k1], vcc\n\t" \
             "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
 
 #define GPUAR_BC_TAIL_PLAIN \
-         /* ---- low record rebuilt -> v204-v207 (written back by the next step) */ \
-            "v_cndmask_b32 %[t3], 0, %[k64k], vcc\n\t" \
-            "v_add_u32 %[lbw], %[lbw], %[t3]\n\t" \
+         /* ---- the low half updated -> v204:v205 (written back by the next step) */ \
+            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" \
+            "v_add_u32 v204, %[lbw], %[t3]\n\t" \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 %[t2], 0, %[t2], %[lmc]\n\t" \
-            "v_add_u32 %[lcc], %[lcc], %[t2]\n\t" \
-            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t" \
-            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t" \
-            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t" \
-            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t" \
-            "v_addc_co_u32 v204, %[mj], v204, 0, %[lma]\n\t" \
-            "v_add_u32 v205, 1, v205\n\t" /* S counts every symbol that lands in the record */
+            "v_add_u32 v205, %[lcc], %[t2]\n\t"
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
@@ -609,13 +598,13 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
         GPUAR_STEP_LOCALS \
+        unsigned long long lma_; \
         asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
             : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "+s"(lma), [lmc] "+s"(lmc), \
-              "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) \
-            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v216"); \
+              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "=&s"(lma_), [lmc] "+s"(lmc) \
+            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
 
@@ -627,10 +616,10 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_PLAIN \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
-              "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) \
-            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216"); \
+              "+v"(o0), "+v"(o1) \
+            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
 
@@ -638,12 +627,12 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 constexpr uint32_t kRingPieces = 4;                        // 16-byte pieces per lane: 64 bytes of stream
 constexpr uint32_t kDecodeLdsQuads = (kDecodeRecords + kRingPieces) * kLanes;
 
-// `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit.  `col` = this lane's 16-byte
-// column of the workgroup's LDS (36 model records, 1024 bytes apart); `ring` = this lane's dword 0 in the 4 KiB
+// `base` is the same in every lane (4-byte aligned); lane offsets are 32-bit.  `col` = this lane's 8-byte
+// column of the workgroup's LDS (72 half-records, 512 bytes apart); `ring` = this lane's dword 0 in the 4 KiB
 // stream-ring region behind the records (16 dwords per lane, 256 bytes apart; the region is 4 KiB-aligned).
 __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
                                             uint8_t *out, bool live) {
-    DecoderLane<10> dec;
+    DecoderLane<9> dec;
     dec.open(col, base, pkt_off, limit_off, live);
     const uint32_t len_max = wave_max(dec.ulen);
     // Whole blocks of 64 symbols: the 64 output bytes gather in 16 registers and leave as four
@@ -662,24 +651,19 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // boundary of LDS (the kernels' only __shared__ array is declared that way); anything else is a build error
     // that would decode garbage, so it stops the kernel instead
     if ((ring_lds & 0xF00u) != 0u) __builtin_trap();
-    register uint32_t o0 asm("v204");          // PLAIN: low record of the previous symbol, rebuilt, not yet written back
+    register uint32_t o0 asm("v204");          // PLAIN: the low half of the previous symbol, updated, not yet written back
     register uint32_t o1 asm("v205");
-    register uint32_t o2 asm("v206");
-    register uint32_t o3 asm("v207");
-    register uint32_t r0 asm("v212");          // CARRIED: low record of the previous symbol as read; the next step rebuilds it
-    register uint32_t r1 asm("v213");          // (path in lma / lincb / lx / lmc) and writes it back in the shadow of its read
-    register uint32_t r2 asm("v214");
-    register uint32_t r3 asm("v215");
     register uint32_t offr asm("v217");        // code - lo; v216:v217 is the pair the 64-bit shift of the window works on
     offr = dec.off;
     uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
-    uint32_t oaddr = col_lds + dec.model.owed.rec - SubtreeModel<10>::kLowBase;      // the write carries offset:4096
+    const uint32_t col_low_lds = col_lds + SubtreeModel<9>::kLowBase;               // ... and of its first low half
+    uint32_t oaddr = col_lds + dec.model.owed.at;                                   // where the half owed goes
     // min over the symbols of Z at the leaf (as u32).  A symbol owns the code value iff the remainder ends below
     // the upper end of its leaf, Z = R - V < 0, i.e. >= 2^31 as u32 (|Z| < 2^30); a code value beyond the model's
     // total (off >= range, where the reference stops decoding, :873-877) walks right everywhere and ends with Z >= 0
     uint32_t bad_min = 0xFFFFFFFFu;
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
-    const uint32_t k64k = 0x10000u;
+    const uint32_t k64k = 0x10000u, k64k1 = 0x10001u;
     uint32_t bswap_sel, ring_wrap;
     asm volatile("s_mov_b32 %0, 0x00010203" : "=s"(bswap_sel));     // (through asm: a known constant would be spliced in as a literal)
     asm volatile("s_movk_i32 %0, 0xf00" : "=s"(ring_wrap));        // 256 * 15: the ring's dword index, scaled
@@ -800,31 +784,23 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
     {
         uint32_t lbw, lcc, lincb, lx;
-        unsigned long long lma, lmc;
-        // The write-back the plain step still owes, in carried form: with empty lane masks the rebuild
-        // yields (lbw + lincb, r1 + 1, lcc, r3).  (Initial values go through asm: a known constant would be
+        unsigned long long lmc;
+        // The write-back the plain step still owes, in carried form: with no increments and an empty lane mask the
+        // update yields (lbw, lcc) as they are.  (Initial values go through asm: a known constant would be
         // spliced into the statements as an immediate.)
-        asm volatile("s_mov_b64 %0, 0\n\ts_mov_b64 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\tv_mov_b32 %4, 0\n\tv_mov_b32 %5, 0"
-                     : "=s"(lma), "=s"(lmc), "=v"(lincb), "=v"(lx), "=v"(r0), "=v"(r2));
-        lbw = dec.model.owed.w0, r1 = dec.model.owed.w1 - 1u, lcc = dec.model.owed.w2, r3 = dec.model.owed.w3;
+        asm volatile("s_mov_b64 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0" : "=s"(lmc), "=v"(lincb), "=v"(lx));
+        lbw = dec.model.owed.w0, lcc = dec.model.owed.w1;
         for (; i + 64u <= len_min; i += 64u) {
             GPUAR_ROTATE_RECIPS
             GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
         }
-        // rebuild the low record still owed the way the step does: v204-v207 then hold what is to be written
+        // update the low half still owed the way the step does: v204:v205 then hold what is to be written
         asm volatile(
-            "v_add_u32 %[lbw], %[lbw], %[lincb]\n\t"
+            "v_add_u32 v204, %[lbw], %[lincb]\n\t"
             "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t"
-            "v_add_u32 %[lcc], %[lcc], %[lx]\n\t"
-            "v_cndmask_b32 v204, %[lbw], v212, %[lma]\n\t"
-            "v_cndmask_b32 v205, v213, %[lbw], %[lma]\n\t"
-            "v_cndmask_b32 v206, %[lcc], v214, %[lma]\n\t"
-            "v_cndmask_b32 v207, v215, %[lcc], %[lma]\n\t"
-            "v_addc_co_u32 v204, vcc, v204, 0, %[lma]\n\t"
-            "v_add_u32 v205, 1, v205\n\t"
-            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx)
-            : [lincb] "v"(lincb), [lma] "s"(lma), [lmc] "s"(lmc), "v"(r0), "v"(r1), "v"(r2), "v"(r3)
-            : "vcc");
+            "v_add_u32 v205, %[lcc], %[lx]\n\t"
+            : "=&v"(o0), "=&v"(o1), [lx] "+v"(lx)
+            : [lbw] "v"(lbw), [lcc] "v"(lcc), [lincb] "v"(lincb), [lmc] "s"(lmc));
     }
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
     //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
@@ -843,8 +819,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     dec.next = (next64 >> 6) - skew16;
     dec.off = offr;
     dec.owed_bits = nbits;
-    dec.model.owed.rec = oaddr - col_lds + SubtreeModel<10>::kLowBase;
-    dec.model.owed.w0 = o0, dec.model.owed.w1 = o1, dec.model.owed.w2 = o2, dec.model.owed.w3 = o3;
+    dec.model.owed.at = oaddr - col_lds;
+    dec.model.owed.w0 = o0, dec.model.owed.w1 = o1;
     dec.bad = dec.bad || bad_min < 0x80000000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
@@ -863,12 +839,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 
 __global__ void __launch_bounds__(kLanes)
 decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];    // 40 KiB: 36 records x 64 lanes x 16 B, then 4 KiB of stream rings
+    __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];    // 40 KiB: 72 half-records x 64 lanes x 8 B, then 4 KiB of stream rings
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
     const uint8_t *group_slots = slots + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);      // wave-uniform
-    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, (lane + 1u) * kSlot,
+    decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, (lane + 1u) * kSlot,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 
@@ -889,7 +865,7 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint64_t left = offsets[n_packets] - first;                       // bytes from the base to the end of the stream
     const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
     const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
-    decode_wave(reinterpret_cast<uint8_t *>(lds + lane), reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_stream, pkt_off, limit_off,
+    decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_stream, pkt_off, limit_off,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
 }
 

@@ -46,7 +46,7 @@ size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
 // ... and the decoder lane program
 size_t decode_one(const uint8_t *pkt, const uint8_t *limit, uint8_t *out) {
     alignas(16) uint8_t records[gpuar::kDecodeRecords * 16];
-    gpuar::DecoderLane<4> dec;
+    gpuar::DecoderLane<3> dec;
     const size_t readable = static_cast<size_t>(limit - pkt);
     dec.open(records, pkt, 0, readable < 0x7FFFFFFFu ? static_cast<uint32_t>(readable) : 0x7FFFFFFFu, true);
     for (uint32_t i = 0; i < dec.ulen; ++i) dec.step(i, kDecode.c[i], out);

@@ -130,6 +130,27 @@ GPUAR_LANE void store128(uint8_t *at, uint32_t a, uint32_t b, uint32_t c, uint32
     memcpy(at, w, 16);
 #endif
 }
+struct Pair {
+    uint32_t w[2];
+};
+GPUAR_LANE Pair load64(const uint8_t *at) {
+    Pair q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint2 v = *reinterpret_cast<const uint2 *>(at);
+    q.w[0] = v.x, q.w[1] = v.y;
+#else
+    memcpy(q.w, at, 8);
+#endif
+    return q;
+}
+GPUAR_LANE void store64(uint8_t *at, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint2 *>(at) = make_uint2(a, b);
+#else
+    const uint32_t w[2] = {a, b};
+    memcpy(at, w, 8);
+#endif
+}
 GPUAR_LANE void store16(uint8_t *at, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     *reinterpret_cast<uint16_t *>(at) = static_cast<uint16_t>(v);
@@ -451,18 +472,19 @@ struct CoderLane {
 // (getSymbolFromProbability :727-763) touches LDS in two round trips of one
 // 16-byte read each instead of walking eight levels.  Depths 0 and 1 of the
 // left-count tree live in registers; depths 2..4 and 5..7 are stored as
-// 3-level subtrees, each one 16-byte RECORD of eight u16 (seven nodes and one
-// spare slot; exact order at decide3) so a single ds_read_b128 fetches everything the next three decisions can
-// need, and those decisions are then taken in registers.  (Measured with
-// tools/lds_probe.hip: at these occupancies a u16 LDS read costs the CU about
-// as much as a 16-byte one.)  Same left-count tree as the encoder's, same
-// counts, same sums, same symbols.
+// 3-level subtrees, each one RECORD of two 8-byte halves (the seven nodes and the
+// count under the root's right child; exact order at decide3) so a single
+// ds_read2_b64 fetches everything the next three decisions can need, those
+// decisions are then taken in registers, and ONE 8-byte store puts back the half
+// the path went through.  (Measured with tools/lds_probe.hip: at these occupancies
+// a u16 LDS read costs the CU about as much as a 16-byte one.)  Same left-count
+// tree as the encoder's, same counts, same sums, same symbols.
 //   records  0..3   : subtrees rooted at the depth-2 nodes (index = complemented top 2 symbol bits)
-//   records  4..35  : subtrees rooted at the depth-5 nodes (index = complemented top 5 symbol bits);
-//                     their spare slot holds S = the count of all eight symbols under the record
-// kRecShift = log2(bytes between consecutive records of one lane): 10 on the
-// GPU (64 lanes x 16 B, lane-minor: any 16 lanes of a ds_read_b128 group cover
-// all 64 banks whatever records they address), 4 on the host.
+//   records  4..35  : subtrees rooted at the depth-5 nodes (index = complemented top 5 symbol bits)
+//   half 2r + h of record r sits at col + ((2r + h) << kHalfShift): its index is the path so far, one bit longer
+// kHalfShift = log2(bytes between consecutive halves of one lane): 9 on the
+// GPU (64 lanes x 8 B, lane-minor: the lanes of a 64-bit access cover all banks
+// whatever halves they address), 3 on the host.
 //
 // THE WALK WORKS ON A SCALED REMAINDER.  The reference forms
 //     unscaled = (((code - lower) + 1) * total - 1) / range          (getUnscaledCode :703-716)
@@ -477,42 +499,39 @@ struct CoderLane {
 // no lane-mask select on the critical chain.  At the leaf R0 - R = cumLo*range
 // is the very numerator applySymbolRange (:256-299) divides by total, and
 // cnt*range for the upper bound comes from S and the three products of the low
-// record: width(left child) = a, width(right child) = width(parent) - a.
+// record: width(left child) = a, width(right child) = width(parent) - a;
+// S = a + aR, the two counts at the head of a record's halves.
 // ===========================================================================
-template <uint32_t kRecShift>
+template <uint32_t kHalfShift>
 struct SubtreeModel {
-    // What three decisions inside one record leave to be written back: the whole record with the
-    // three nodes on the path incremented where the walk went left (and S + 1 in a low record) --
-    // ONE 16-byte store.  (Three u16 stores of just the changed nodes need fewer vector
-    // instructions but two more LDS instructions per record, and an LDS instruction is the dearer
-    // of the two here.)
+    // What three decisions inside one record leave to be written back: the HALF of the record the first
+    // decision chose, with +1 on its count (a or aR: every symbol that lands in the record lands in one of
+    // the two halves), on the child if the second decision went left and on the grandchild if the third
+    // did -- ONE 8-byte store at an address that is one shift-add of the path, no select.
     struct Path {
-        uint32_t rec;                   // byte offset of the record from `col`
-        uint32_t w0, w1, w2, w3;
+        uint32_t at;                    // byte offset of the half from `col`
+        uint32_t w0, w1;
     };
 
-    uint8_t *col;                       // this lane's 16-byte column
+    uint8_t *col;                       // this lane's 8-byte column
     uint32_t root, half0, half1;        // depth 0; depth 1 under root's left / right child
     Path owed;                          // write-back of the previous symbol's low record, not yet issued
 
-    static constexpr uint32_t kRecords = kDecodeRecords;
-    static constexpr uint32_t kLowBase = 4u << kRecShift;      // byte offset of low record 0
+    static constexpr uint32_t kHalves = 2u * kDecodeRecords;
+    static constexpr uint32_t kHalf = 1u << kHalfShift;        // bytes between the two halves of a record
+    static constexpr uint32_t kLowBase = 8u << kHalfShift;     // byte offset of low record 0 (behind the 4 mid records)
 
     GPUAR_LANE void reset() {
         root = 128u;
         half0 = half1 = 64u;
-        // nothing owed yet: a write-back that rewrites record 35 with its initial values
-        owed.rec = (kRecords - 1u) << kRecShift;
+        // nothing owed yet: a write-back that rewrites the last half with its initial values
+        owed.at = (kHalves - 1u) << kHalfShift;
         owed.w0 = 4u | (2u << 16);
-        owed.w1 = 8u | (2u << 16);
-        owed.w2 = owed.w3 = 1u | (1u << 16);
+        owed.w1 = 1u | (1u << 16);
 #pragma unroll 1
-        for (uint32_t r = 0; r < kRecords; ++r) {
-            const uint32_t top = r < 4u ? 32u : 4u;       // value of a depth-2 / depth-5 node
-            const uint32_t ab = top | ((top >> 1) << 16);          // a, bR
-            const uint32_t xb = (r < 4u ? 0u : 8u) | ((top >> 1) << 16);   // S (low records) / unused, bL
-            const uint32_t cc = (top >> 2) | ((top >> 2) << 16);   // cRR, cRL ; cLR, cLL
-            store128(col + (r << kRecShift), ab, xb, cc, cc);
+        for (uint32_t h = 0; h < kHalves; ++h) {
+            const uint32_t top = h < 8u ? 32u : 4u;       // count under a child of a depth-2 / depth-5 node
+            store64(col + (h << kHalfShift), top | ((top >> 1) << 16), (top >> 2) * 0x10001u);
         }
     }
 
@@ -524,55 +543,53 @@ struct SubtreeModel {
         return left;
     }
 
-    // Three decisions inside the record whose 16 bytes are `q`.  `npath` = the
+    // Three decisions inside the record whose halves are `right` and `left`.  `npath` = the
     // COMPLEMENTED symbol bits decided so far, MSB first: every decision is kept
     // as "went LEFT" -- that is what the borrow of the subtraction says, what the
     // node update adds, and npath = 2 * npath + left is one add-with-carry of it;
-    // records and the nodes inside them are simply stored in complemented order
-    // so that npath indexes them directly.  Record layout (the two candidates of
-    // a decision sit in the same half of two dwords, so one select picks both
-    // grandchildren at once; L/R = left/right child):
-    //     w0 = a | bR << 16     w1 = S | bL << 16     w2 = cRR | cRL << 16     w3 = cLR | cLL << 16
-    // kLow: the record is a low one -- also returns W = cnt(symbol) * range through `width`.
+    // records, halves and the nodes inside them are simply stored in complemented
+    // order so that npath indexes them directly.  A record is two halves of 8 bytes,
+    // one per child of its root (L/R = left/right child of the node before):
+    //     right half:  aR | bR << 16,  cRR | cRL << 16        (half 2r of the lane's column)
+    //     left half:   a  | bL << 16,  cLR | cLL << 16        (half 2r + 1)
+    // a = symbols counted in the root's LEFT subtree (the node of the tree proper), aR = in its right one;
+    // b, c: the left-counts of the child and of the grandchildren on that side.  The first decision needs a,
+    // the next two only the half it chose -- and only that half changes.
+    // `base`: byte offset of the record's right half.  kLow: the record is a low one -- also returns
+    // W = cnt(symbol) * range through `width`.
     template <bool kLow>
-    GPUAR_LANE Path decide3(uint32_t rec, const Quad &q, uint32_t range, uint32_t &R, uint32_t &npath, uint32_t &width) {
-        const uint32_t *w = q.w;
-        const uint32_t pa = GPUAR_MUL24_VV(w[0] & 0xFFFFu, range);
+    GPUAR_LANE Path decide3(uint32_t base, const Pair &right, const Pair &left, uint32_t range, uint32_t &R, uint32_t &npath,
+                            uint32_t &width) {
+        const uint32_t pa = GPUAR_MUL24_VV(left.w[0] & 0xFFFFu, range);
         const bool la = decide(R, pa);
-        const uint32_t bw = la ? w[1] : w[0];                 // the chosen child sits in its high half
-        const uint32_t cc = la ? w[3] : w[2];                 // both grandchildren under the chosen child
+        const uint32_t bw = la ? left.w[0] : right.w[0];      // the chosen child sits in its high half
+        const uint32_t cc = la ? left.w[1] : right.w[1];      // both grandchildren under the chosen child
         const uint32_t pb = GPUAR_MUL24_VV(bw >> 16, range);
         const bool lb = decide(R, pb);
         const uint32_t pc = GPUAR_MUL24_VV(lb ? cc >> 16 : cc & 0xFFFFu, range);
         const bool lc = decide(R, pc);
         npath = 8u * npath + (la ? 4u : 0u) + (lb ? 2u : 0u) + (lc ? 1u : 0u);
         if (kLow) {
-            const uint32_t ps = GPUAR_MUL24_VV(w[1] & 0xFFFFu, range);
+            const uint32_t ps = GPUAR_MUL24_VV((left.w[0] & 0xFFFFu) + (right.w[0] & 0xFFFFu), range);   // all eight symbols
             const uint32_t gw = la ? pa : ps - pa;             // width of the chosen child, scaled
             const uint32_t pw = lb ? pb : gw - pb;
             width = lc ? pc : pw - pc;
         }
-        // the record with +1 on the path nodes where the walk went left: the child's dword and the
-        // grandchildren's dword are bumped in their selected copies and put back by the same selects
-        const uint32_t bw_new = bw + (lb ? 0x10000u : 0u);
-        const uint32_t cc_new = cc + (lc ? (lb ? 0x10000u : 1u) : 0u);
         Path p;
-        p.rec = rec;
-        p.w0 = (la ? w[0] : bw_new) + (la ? 1u : 0u);         // a sits in the low half of w0
-        p.w1 = (la ? bw_new : w[1]) + (kLow ? 1u : 0u);       // S counts every symbol that lands here
-        p.w2 = la ? w[2] : cc_new;
-        p.w3 = la ? cc_new : w[3];
+        p.at = base + (la ? kHalf : 0u);
+        p.w0 = bw + (lb ? 0x10001u : 1u);
+        p.w1 = cc + (lc ? (lb ? 0x10000u : 1u) : 0u);
         return p;
     }
-    GPUAR_LANE void write_back(const Path &p) { store128(col + p.rec, p.w0, p.w1, p.w2, p.w3); }
+    GPUAR_LANE void write_back(const Path &p) { store64(col + p.at, p.w0, p.w1); }
 
     // The symbol s with cum(s)*range <= R0 < cum(s+1)*range.  On return R = R0 - cum(s)*range
     // and width = cnt(s)*range.  Memory-safe for any R0 (a value beyond the model's total simply
     // walks right).
     // Order of LDS traffic (LDS operations of a wavefront complete in order):
-    //   write back the PREVIOUS symbol's low record -> read mid record -> read low record (a later
-    //   read of the same low record comes after that write) -> write back the mid record ->
-    //   (low record's write-back is owed to the next call / flush()).
+    //   write back the PREVIOUS symbol's low half -> read mid record -> read low record (a later
+    //   read of the same low record comes after that write) -> write back the mid half ->
+    //   (the low half's write-back is owed to the next call / flush()).
     // `in_shadow()` is called right after the first record read has been issued:
     // work that the symbol search does not depend on goes there.
     template <typename Shadow>
@@ -583,21 +600,21 @@ struct SubtreeModel {
         const bool l1 = decide(R, GPUAR_MUL24_VV(h, range));
         uint32_t npath = (l0 ? 2u : 0u) + (l1 ? 1u : 0u);     // complemented top two symbol bits
         write_back(owed);
-        const uint32_t rec_mid = npath << kRecShift;
-        Quad q_mid = load128(col + rec_mid);                  // ds_read_b128 #1
-        GPUAR_PIN_LOAD(q_mid);
+        const uint32_t rec_mid = (2u * npath) << kHalfShift;
+        Pair mid_r = load64(col + rec_mid), mid_l = load64(col + rec_mid + kHalf);   // ds_read2_b64 #1
+        GPUAR_PIN_LOAD(mid_l);
         root += l0 ? 1u : 0u;                                 // register nodes: in the shadow of read #1
         const uint32_t h_new = h + (l1 ? 1u : 0u);            // the depth-1 node on the path
         half0 = l0 ? h_new : half0;
         half1 = l0 ? half1 : h_new;
         in_shadow();
         uint32_t unused = 0;
-        const Path p_mid = decide3<false>(rec_mid, q_mid, range, R, npath, unused);
-        const uint32_t rec_low = kLowBase + (npath << kRecShift);   // npath = complemented top five symbol bits
-        Quad q_low = load128(col + rec_low);                  // ds_read_b128 #2 ...
-        GPUAR_PIN_LOAD(q_low);
-        write_back(p_mid);                                    // ... with the mid record's write-back behind it
-        owed = decide3<true>(rec_low, q_low, range, R, npath, width);
+        const Path p_mid = decide3<false>(rec_mid, mid_r, mid_l, range, R, npath, unused);
+        const uint32_t rec_low = kLowBase + ((2u * npath) << kHalfShift);   // npath = complemented top five symbol bits
+        Pair low_r = load64(col + rec_low), low_l = load64(col + rec_low + kHalf);   // ds_read2_b64 #2 ...
+        GPUAR_PIN_LOAD(low_l);
+        write_back(p_mid);                                    // ... with the mid half's write-back behind it
+        owed = decide3<true>(rec_low, low_r, low_l, range, R, npath, width);
         return npath ^ 255u;
     }
 

@@ -53,7 +53,7 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
     std::vector<uint64_t> records(kDecodeRecords * 2);       // 16 bytes each, 8-byte aligned storage
     const uint8_t *limit = stream + pkt_offsets[np];
     for (size_t p = 0; p < np; ++p) {
-        DecoderLane<4> dec;
+        DecoderLane<3> dec;
         uint8_t *o = out + p * kPacket;
         const uint64_t readable = static_cast<uint64_t>(limit - (stream + pkt_offsets[p]));
         dec.open(reinterpret_cast<uint8_t *>(records.data()), stream + pkt_offsets[p], 0,
