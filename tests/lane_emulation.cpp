@@ -44,6 +44,46 @@ int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     return any_overflow;
 }
 
+// The same the way the kernel's three roles run it: in phases of 8 symbols, the top modeler's parts first, the
+// low modeler one phase later adding its own ONTO them -- without a look at the next phase (prime() at the start
+// of a phase, step_last() for its last symbol) -- and the coder behind both.
+int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+{
+    int any_overflow = 0;
+    const size_t np = (n_bytes + kPacket - 1) / kPacket;
+    std::vector<uint16_t> table(kTreeRows);
+    constexpr uint32_t kPhase = 8;
+    for (size_t p = 0; p < np; ++p) {
+        const size_t off = p * kPacket;
+        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
+        TopModeler<1> top;
+        LowModeler<1> low;
+        top.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
+        low.open(reinterpret_cast<uint8_t *>(table.data()), 0, 0);
+        CoderLane coder;
+        coder.open(slots, static_cast<uint32_t>(p * kSlot));
+        for (uint32_t base = 0; base < len; base += kPhase) {
+            const uint32_t count = len - base < kPhase ? len - base : kPhase;
+            uint32_t sums[kPhase];
+            for (uint32_t j = 0; j < count; ++j) {
+                const uint32_t i = base + j;
+                sums[j] = top.step(in[off + i], 256u + i, i + 1 < len ? in[off + i + 1] : 0u);
+            }
+            low.prime(in[off + base]);
+            for (uint32_t j = 0; j < count; ++j) {
+                const uint32_t i = base + j;
+                sums[j] = j + 1 < count ? low.step(in[off + i], 256u + i, in[off + i + 1], sums[j])
+                                        : low.step_last(in[off + i], 256u + i, sums[j]);
+            }
+            for (uint32_t j = 0; j < count; ++j) coder.step(sums[j], kRecip.r[base + j]);
+        }
+        bool ov;
+        coder.finish(len, ov);
+        any_overflow |= ov ? 1 : 0;
+    }
+    return any_overflow;
+}
+
 // What a decoder wavefront's lane does (SubtreeModel + DecoderLane).
 // pkt_offsets: np+1 byte offsets into `stream`; out: np * 8192 bytes.
 // Returns the number of packets flagged bad.

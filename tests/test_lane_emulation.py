@@ -35,6 +35,8 @@ def emu():
     lib = C.CDLL(so)
     lib.emu_encode_slots.restype = C.c_int
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_phased.restype = C.c_int
+    lib.emu_encode_slots_phased.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
@@ -82,6 +84,17 @@ def emu_decode(lib, stream, offs, npk):
     out = np.zeros(max(npk, 1) * 8192, dtype=np.uint8)
     bad = lib.emu_decode_stream(padded.ctypes.data_as(u8p), offs.ctypes.data_as(u64p), npk, out.ctypes.data_as(u8p))
     return out, bad
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_phased_modelers_give_the_same_slots(emu, c):
+    """The encode kernel's roles run a phase apart: the low modeler adds onto the top modeler's parts and never sees
+    the phase behind its own (PartialModeler::prime / step_last / `onto`).  Same slots as the straight emulation."""
+    data = np.ascontiguousarray(case_input(c))
+    want, npk, ov = emu_encode(emu, data)
+    got = np.zeros_like(want)
+    assert emu.emu_encode_slots_phased(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov
+    assert np.array_equal(got, want)
 
 
 def test_reciprocal_table_is_exact(emu):
