@@ -566,14 +566,12 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_STREAM_TEXT \
             "v_sub_co_u32 %[rem], vcc, %[rem], %[n]\n\t" /* borrow: w0 ran out */ \
             "v_and_b32 %[rem], 31, %[rem]\n\t" \
-            "s_and_saveexec_b64 %[sx], vcc\n\t" \
-            "s_cbranch_execz 1f\n\t" \
+            "s_and_saveexec_b64 %[sx], vcc\n\t" /* (no branch around the region: some lane refills on almost every symbol) */ \
             "v_mov_b32 %[w0], %[w1]\n\t" \
             "v_perm_b32 %[w1], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
             "v_and_or_b32 %[t0], %[next], %[kf00], %[ring]\n\t" /* ring + 256 * (dword index mod 16) */ \
             "ds_read_b32 %[ahead], %[t0]\n\t" \
             "v_add_u32 %[next], 0x100, %[next]\n\t" \
-            "1:\n\t" \
             "s_or_b64 exec, exec, %[sx]\n\t" \
             "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t" /* the next 32 stream bits */
 
