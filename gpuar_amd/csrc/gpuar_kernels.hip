@@ -647,8 +647,11 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));  // ... and of dword 0 of its stream ring
     // the refill's address arithmetic ORs a dword index into bits 8-11: the ring region must start on a 4 KiB
     // boundary of LDS (the kernels' only __shared__ array is declared that way); anything else is a build error
-    // that would decode garbage, so it stops the kernel instead
-    if ((ring_lds & 0xF00u) != 0u) __builtin_trap();
+    // that would decode garbage, so the wavefront flags every packet bad and decodes nothing instead
+    if ((ring_lds & 0xF00u) != 0u) {
+        atomicOr(&g_status, GPUAR_STATUS_BAD_PACKET);
+        return;
+    }
     register uint32_t o0 asm("v204");          // PLAIN: the low half of the previous symbol, updated, not yet written back
     register uint32_t o1 asm("v205");
     register uint32_t offr asm("v217");        // code - lo; v216:v217 is the pair the 64-bit shift of the window works on
