@@ -49,8 +49,8 @@ KERNEL_SOURCES = ("gpuar_amd/csrc/gpuar_kernels.hip", "gpuar_amd/csrc/lane_codec
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "text"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -58,7 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--total-gib", type=float, default=8.0, help="strong scaling: GiB split over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--cpu-sample-mib", type=int, default=16, help="single-core CPU baseline sample")
+    ap.add_argument("--no-scaling-extras", action="store_true",
+                    help="N > 1: skip the other scaling mode's pass and the gather probe")
     return ap.parse_args(argv)
 
 
@@ -116,37 +118,70 @@ def timed_kernel_ms(fn, reps):
 
 
 def load_profiled_traffic(kind, n_bytes, root=ROOT, stamp=None):
-    """HBM bytes per launch (and the issue-side counters) from the newest profiles/*_traffic.json --
-    the PMC passes of rocprofv3 (tools/prof.sh + tools/traffic_from_prof.py); counters cannot be
-    collected from inside this process.  The record is used only if it was taken on this workload
-    size and stream kind AND on the kernel sources that are built now (sha256 stamp); otherwise
-    traffic is null and `traffic_source` says why."""
+    """HBM bytes per launch (and the issue-side counters) from the newest profiles/*_traffic*.json taken on THIS
+    workload -- the PMC passes of rocprofv3 (tools/prof.sh + tools/traffic_from_prof.py); counters cannot be
+    collected from inside this process.  A record is used only if it was taken on this workload size and stream kind
+    AND on the kernel sources that are built now (sha256 stamp); otherwise traffic is null and `traffic_source`
+    says why."""
     import glob
-    files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_traffic*.json")))
     if not files:
-        return {"source": "no profiles/*_traffic.json"}
-    name = os.path.basename(files[-1])
-    try:
-        t = json.load(open(files[-1]))
-    except Exception as e:                      # noqa: BLE001 -- a damaged record is reported, not fatal
-        return {"source": f"{name}: unreadable ({e})"}
-    if t.get("kind", "uniform") != kind or abs(t.get("input_gib", 0) * GIB - n_bytes) > 1:
-        return {"source": f"{name}: taken on {t.get('kind', 'uniform')} {t.get('input_gib')} GiB, not this workload"}
+        return {"source": "no profiles/*_traffic*.json"}
+    why = []
     stamp = stamp or kernel_source_stamp(root)
-    if t.get("kernel_source_sha256_16") != stamp:
-        return {"source": f"{name}: STALE -- taken on kernel sources {t.get('kernel_source_sha256_16')}, built sources are "
-                          f"{stamp}; re-run tools/refresh_profiles.sh"}
-    out = {"source": name + ": " + t.get("source", "")}
-    for k in ("encode", "decode"):
-        if k in t:
-            out[k] = t[k]
-    return out
+    for path in reversed(files):
+        name = os.path.basename(path)
+        try:
+            t = json.load(open(path))
+        except Exception as e:                      # noqa: BLE001 -- a damaged record is reported, not fatal
+            why.append(f"{name}: unreadable ({e})")
+            continue
+        if t.get("kind", "uniform") != kind or abs(t.get("input_gib", 0) * GIB - n_bytes) > 1:
+            why.append(f"{name}: taken on {t.get('kind', 'uniform')} {t.get('input_gib')} GiB, not this workload")
+            continue
+        if t.get("kernel_source_sha256_16") != stamp:
+            why.append(f"{name}: STALE -- taken on kernel sources {t.get('kernel_source_sha256_16')}, built sources are "
+                       f"{stamp}; re-run tools/refresh_profiles.sh")
+            continue
+        out = {"source": name + ": " + t.get("source", "")}
+        for k in ("encode", "decode", "decode_stream", "gather"):
+            if k in t:
+                out[k] = t[k]
+        return out
+    return {"source": "; ".join(why[:3])}
+
+
+def usable_cpus():
+    """Host CPUs this process may really use: the affinity mask, cut down by the cgroup's CPU quota
+    (a container on a 256-thread host is typically given a share of it; os.cpu_count() says 256 anyway)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "sched_getaffinity"
+    try:                                                     # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period) + 0.5))
+            if q < n:
+                n, how = q, "cgroup cpu.max"
+    except (OSError, ValueError):
+        try:                                                 # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and max(1, int(quota / period + 0.5)) < n:
+                n, how = max(1, int(quota / period + 0.5)), "cgroup cfs_quota"
+        except (OSError, ValueError):
+            pass
+    return max(1, n), how
 
 
 def cpu_baseline(kind, seed, sample_bytes):
-    """Reference codec (oracle/_ref: the reference's own arCompress/arDecompress) or, if that
-    build is absent, the C port, timed on ONE host core the way the reference times --host
-    (model init + codec call only, src/cpu_compressor.cpp:58-62,157-161)."""
+    """The CPU beside the GPU numbers (a reported baseline, not a target).
+    Row 1: the reference codec (oracle/_ref: the reference's own arCompress/arDecompress; the C port if that build
+    is absent) on ONE host core, timed the way the reference times --host (model init + codec call only,
+    src/cpu_compressor.cpp:58-62,157-161).  Row 2 (`all_cores`): the same codec with the packets fanned out over
+    the host's usable cores by NATIVE threads (oracle/ref_driver.cpp, one contiguous packet range per thread) --
+    packets are independent, so this is the fair "all of the host" ceiling; `cores` is the affinity mask cut down
+    by the cgroup quota, not os.cpu_count().  Row 3 (`product_host`): this repository's own `gpuar-host --host
+    --threads=0` on a file of the same stream, wall time."""
     from gpuar_amd import synth
     from oracle import oracle as O
     codec = O.best()
@@ -158,30 +193,169 @@ def cpu_baseline(kind, seed, sample_bytes):
     t2 = time.perf_counter()
     ok = bool((back == data).all())
     enc, dec = data.size / (t1 - t0) / 1e9, data.size / (t2 - t1) / 1e9
+    cores, how = usable_cpus()
     res = {
         "value": data.size / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": codec.kind,
         "sample": f"first {sample_bytes >> 20} MiB of the same {kind}({seed}) stream, encode then decode, 1 thread",
-        "encode_GBps": enc, "decode_GBps": dec, "roundtrip_ok": ok, "host_cpus": os.cpu_count(),
+        "encode_GBps": enc, "decode_GBps": dec, "roundtrip_ok": ok,
+        "host_cpus_online": os.cpu_count(), "host_cpus_usable": cores, "host_cpus_usable_from": how,
     }
-    # Extra row: the same codec with the packets fanned out over EVERY host core
-    # (one thread per logical CPU, one contiguous packet range each) -- packets are independent, so this is
-    # the fair "all of the host" ceiling.
-    from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, os.cpu_count() or 1)
-    per = (4 << 20) if threads > 64 else (8 << 20)
-    big = synth.generate(kind, seed, threads * per)
-    chunks = [big[t * per:(t + 1) * per] for t in range(threads)]
-    with ThreadPoolExecutor(threads) as pool:            # ctypes calls release the GIL
+    if hasattr(codec, "encode_stream_mt"):
+        per = 8 << 20
+        big = synth.generate(kind, seed, cores * per)
         t0 = time.perf_counter()
-        streams = list(pool.map(codec.encode_stream, chunks))
+        streams = codec.encode_stream_mt(big, cores)
         t1 = time.perf_counter()
-        backs = list(pool.map(lambda sc: codec.decode_stream(sc[0], sc[1].size), zip(streams, chunks)))
+        back = codec.decode_stream_mt(streams, big.size, cores)
         t2 = time.perf_counter()
-    res["all_cores"] = {
-        "cores": threads, "sample": f"{threads} x {per >> 20} MiB of the same stream, one contiguous packet range per thread",
-        "value": big.size / (t2 - t0) / 1e9, "encode_GBps": big.size / (t1 - t0) / 1e9, "decode_GBps": big.size / (t2 - t1) / 1e9,
-        "roundtrip_ok": all(bool((b == c).all()) for b, c in zip(backs, chunks)),
+        res["all_cores"] = {
+            "cores": cores, "threads": "native (oracle/ref_driver.cpp), one contiguous packet range per thread",
+            "sample": f"first {cores} x {per >> 20} MiB of the same stream",
+            "value": big.size / (t2 - t0) / 1e9, "encode_GBps": big.size / (t1 - t0) / 1e9, "decode_GBps": big.size / (t2 - t1) / 1e9,
+            "roundtrip_ok": bool((back == big).all()),
+        }
+        res["all_cores"]["speedup_over_one_core"] = res["all_cores"]["value"] / res["value"]
+    res["product_host"] = product_host_baseline(kind, seed, cores)
+    return res
+
+
+def product_host_baseline(kind, seed, cores, mib_per_core=8):
+    """This repository's own --host path (gpuar-host: lane_codec.h on the CPU, --threads=0 = all cores), wall time of
+    the CLI on a file in the page cache -- file I/O included, as a user of the CLI sees it."""
+    import tempfile
+    from gpuar_amd import synth
+    exe = os.path.join(ROOT, "gpuar_amd", "bin", "gpuar-host")
+    if not os.path.exists(exe):
+        return {"skipped": "gpuar_amd/bin/gpuar-host not built"}
+    n = cores * (mib_per_core << 20)
+    with tempfile.TemporaryDirectory() as d:
+        src, gip, back = (os.path.join(d, x) for x in ("in.dat", "out.gip", "back.dat"))
+        synth.generate(kind, seed, n).tofile(src)
+        t0 = time.perf_counter()
+        c = subprocess.run([exe, "c", "--host", "--threads=0", f"--in={src}", f"--out={gip}"], capture_output=True, text=True)
+        t1 = time.perf_counter()
+        dd = subprocess.run([exe, "d", "--host", "--threads=0", f"--in={gip}", f"--out={back}"], capture_output=True, text=True)
+        t2 = time.perf_counter()
+        ok = c.returncode == 0 and dd.returncode == 0 and open(back, "rb").read() == open(src, "rb").read()
+    return {"what": "gpuar-host c|d --host --threads=0 (this repository's CPU path), CLI wall time incl. file I/O",
+            "cores": cores, "sample": f"{n >> 20} MiB of the same stream", "value": n / (t2 - t0) / 1e9, "unit": "GB/s",
+            "encode_GBps": n / (t1 - t0) / 1e9, "decode_GBps": n / (t2 - t1) / 1e9, "roundtrip_ok": ok}
+
+
+def hbm_roof(bytes_per_launch, ms):
+    a = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None}
+
+
+def side_kernels(H, d_in, d_slots, d_out, npk, n, reps):
+    """The kernels either side of the two coder kernels, timed like them (HIP events on the launch stream,
+    untimed region): the device-side compaction (scan + gather: the one HBM-bound piece, SURVEY.md 8(d) "include its
+    time in t_kernel"), encode + compaction back to back (the device side of `gpuar c`), and decode_stream_kernel --
+    the decoder `gpuar d` really runs, reading the compacted stream instead of the slots."""
+    import torch
+    d_stream = torch.empty(npk * H.SLOT + 16, dtype=torch.uint8, device=d_in.device)
+    d_off = torch.empty(npk + 1, dtype=torch.int64, device=d_in.device)
+    compact_ms = timed_kernel_ms(lambda: H.compact(d_slots, npk, d_stream, d_off), reps)
+
+    def both():
+        H.encode(d_in, d_slots)
+        H.compact(d_slots, npk, d_stream, d_off)
+
+    enc_compact_ms = timed_kernel_ms(both, reps)
+    d_out.zero_()
+    dstream_ms = timed_kernel_ms(lambda: H.decode_stream(d_stream, d_off, npk, d_out), reps)
+    torch.cuda.synchronize()
+    c = int(d_off[-1].item())
+    ok = bool(torch.equal(d_out[:n], d_in))
+    avg = lambda v: sum(v) / len(v)                                                   # noqa: E731
+    out = {
+        "compact_ms": avg(compact_ms), "encode_plus_compact_ms": avg(enc_compact_ms), "decode_stream_ms": avg(dstream_ms),
+        "decode_stream_roundtrip_equal": ok,
+        # compaction reads the C defined bytes of the slots and writes them once (+ 2 bytes of header per packet for the scan)
+        "roofline_compact": dict(hbm_roof(2 * c + 2 * npk, avg(compact_ms)), kernel="scan_* + gather_kernel"),
+        "roofline_decode_stream": dict(hbm_roof(n + c + 8 * npk, avg(dstream_ms)), kernel="decode_stream_kernel"),
+        "encode_plus_compact_GBps": n / (avg(enc_compact_ms) * 1e-3) / 1e9,
+        "decode_stream_GBps": n / (avg(dstream_ms) * 1e-3) / 1e9,
     }
+    return out, d_stream, d_off, c
+
+
+def gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl):
+    """north_star: "RCCL over xGMI only if a gather is measurably cheaper than staged hipMemcpyAsync" -- measured,
+    on a bounded sample of every rank's compacted segment:
+      staged  : every rank copies its segment to its OWN pinned host buffer over its own PCIe link, all at once
+      gathered: every rank sends its segment to rank 0 (RCCL send/recv over xGMI), rank 0 copies the whole to the host
+    Both leave all segments in host memory, ready for the ordered write.  Times are the MAX over ranks."""
+    import torch
+    t = torch.tensor([min(c_bytes, 256 << 20)], dtype=torch.int64, device=ctl_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    sample = int(t.item()) // 4096 * 4096
+    seg = d_stream[:sample]
+    dev = seg.device
+    h_own = torch.empty(sample, dtype=torch.uint8, pin_memory=True)
+    h_all = torch.empty(sample * world, dtype=torch.uint8, pin_memory=True) if rank == 0 else None
+    d_all = torch.empty(sample * world, dtype=torch.uint8, device=dev) if rank == 0 else None
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(sec):
+        v = torch.tensor([sec], dtype=torch.float64, device=ctl_dev)
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def staged():
+        h_own.copy_(seg, non_blocking=True)
+        torch.cuda.synchronize()
+
+    def gathered():
+        if world > 1:
+            if on_rccl:
+                ops = []
+                if rank == 0:
+                    for r in range(1, world):
+                        ops.append(dist.P2POp(dist.irecv, d_all[r * sample:(r + 1) * sample], r))
+                else:
+                    ops.append(dist.P2POp(dist.isend, seg, 0))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            else:                   # test mode (gloo, ranks share one GPU): host tensors stand in for the xGMI hop
+                if rank == 0:
+                    for r in range(1, world):
+                        buf = torch.empty(sample, dtype=torch.uint8)
+                        dist.recv(buf, r)
+                        d_all[r * sample:(r + 1) * sample].copy_(buf)
+                else:
+                    dist.send(seg.cpu(), 0)
+        if rank == 0:
+            d_all[:sample].copy_(seg)
+            h_all.copy_(d_all, non_blocking=True)
+        torch.cuda.synchronize()
+
+    res = {}
+    for name, fn in (("staged_d2h_ms", staged), ("gather_then_d2h_ms", gathered)):
+        fn()                                                   # warm-up (first touch of the pinned pages, RCCL channels)
+        best = None
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            fn()
+            sync()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            best = dt if best is None else min(best, dt)
+        res[name] = best * 1e3
+    res.update({
+        "bytes_per_rank": sample, "ranks": world,
+        "transport": "RCCL send/recv to rank 0" if on_rccl else "gloo on host tensors (test mode, ranks share one GPU)",
+        "staged_GBps": sample * world / (res["staged_d2h_ms"] * 1e-3) / 1e9,
+        "gathered_GBps": sample * world / (res["gather_then_d2h_ms"] * 1e-3) / 1e9,
+        "cheaper": "staged hipMemcpyAsync" if res["staged_d2h_ms"] <= res["gather_then_d2h_ms"] else "RCCL gather",
+    })
     return res
 
 
@@ -234,6 +408,76 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
     }
 
 
+def run_pass(args, H, dist, world, rank, dev, ctl_dev, steps, warmup):
+    """One measurement of the hot path under args.scaling: this rank's shard generated on the device, W untimed
+    warm-up steps, then exactly `steps` steps (encode kernel + decode kernel) bracketed by barrier +
+    torch.cuda.synchronize(), MAX over ranks; then, untimed, the per-kernel durations and the checks of what was
+    just timed.  Returns plain numbers plus the device buffers (for the side kernels and the gather probe)."""
+    import torch
+    offset, n = plan_shard(args, world, rank)
+    if n == 0:
+        raise SystemExit(f"rank {rank} has no packets: too little data for {world} GPUs")
+    npk = H.packet_count(n)
+    d_in = H.generate(args.kind, args.seed, n, offset=offset, device=dev)
+    d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(npk * H.PACKET, dtype=torch.uint8, device=dev)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)      # this rank's own status word (include/gpuar_hip.h d_status)
+
+    def encode():
+        H.encode(d_in, d_slots, d_status=word)
+
+    def decode():
+        H.decode(d_slots, npk, d_out, d_status=word)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        encode()
+        decode()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        encode()
+        decode()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), untimed region ----
+    reps = max(3, min(steps, 10))
+    enc_ms = timed_kernel_ms(encode, reps)
+    dec_ms = timed_kernel_ms(decode, reps)
+    enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
+
+    # ---- correctness of what was just timed ----
+    torch.cuda.synchronize()
+    status = int(word.item()) | H.status()
+    roundtrip_equal = bool(torch.equal(d_out[:n], d_in))
+    sample = min(n, 64 << 20)
+    md5_in = hashlib.md5(d_in[:sample].cpu().numpy().tobytes()).hexdigest()
+    md5_out = hashlib.md5(d_out[:sample].cpu().numpy().tobytes()).hexdigest()
+    return {"n": n, "npk": npk, "elapsed": elapsed, "enc_ms": enc_avg, "dec_ms": dec_avg, "status": status,
+            "roundtrip_equal": roundtrip_equal, "md5_in": md5_in, "md5_out": md5_out,
+            "d_in": d_in, "d_slots": d_slots, "d_out": d_out}
+
+
+def gather_rows(dist, world, ctl_dev, row):
+    """all_gather of one int64 row per rank (rank order)."""
+    import torch
+    mine = torch.tensor(row, dtype=torch.int64, device=ctl_dev)
+    if world == 1:
+        return [mine.tolist()]
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    return [r.tolist() for r in rows]
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -259,6 +503,7 @@ def main(argv=None):
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     ctl_dev = dev                      # where the control tensors of the collectives live
+    on_rccl = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if oversubscribe:
@@ -266,85 +511,70 @@ def main(argv=None):
             ctl_dev = torch.device("cpu")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            on_rccl = True
     H.load()
 
-    # ---- this rank's shard: contiguous packet range of the global stream ----
-    offset, n = plan_shard(args, world, rank)
-    if n == 0:
-        raise SystemExit(f"rank {rank} has no packets: too little data for {world} GPUs")
-    npk = H.packet_count(n)
-    d_in = H.generate(args.kind, args.seed, n, offset=offset, device=dev)
-    d_slots = torch.empty(npk * H.SLOT, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(npk * H.PACKET, dtype=torch.uint8, device=dev)
-
-    def encode():
-        H.encode(d_in, d_slots)
-
-    def decode():
-        H.decode(d_slots, npk, d_out)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        encode()
-        decode()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        encode()
-        decode()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- per-kernel durations (HIP events on the launch stream), untimed region ----
-    reps = max(3, args.steps)
-    enc_ms = timed_kernel_ms(encode, reps)
-    dec_ms = timed_kernel_ms(decode, reps)
-    enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
-
-    # ---- correctness of what was just timed ----
-    status = H.status()
-    d_stream, d_off = H.compact(d_slots, npk)
-    c_bytes = int(d_off[-1].item())
-    roundtrip_equal = bool(torch.equal(d_out[:n], d_in))
-    sample = min(n, 64 << 20)
-    md5_in = hashlib.md5(d_in[:sample].cpu().numpy().tobytes()).hexdigest()
-    md5_out = hashlib.md5(d_out[:sample].cpu().numpy().tobytes()).hexdigest()
+    # ---- the pass the contract's `value` comes from ----
+    P = run_pass(args, H, dist, world, rank, dev, ctl_dev, args.steps, args.warmup)
+    n, npk = P["n"], P["npk"]
+    # ---- the kernels either side (compaction, encode + compaction, decode from the stream), untimed region ----
+    side, d_stream, d_off, c_bytes = side_kernels(H, P["d_in"], P["d_slots"], P["d_out"], npk, n, reps=5)
     oracle_ok = None
     if rank == 0:
         from oracle import oracle as O
         k = min(64, npk)
-        host = d_in[:min(n, k * H.PACKET)].cpu().numpy()
+        host = P["d_in"][:min(n, k * H.PACKET)].cpu().numpy()
         want = O.best().encode_stream(host)
         got = d_stream[:int(d_off[k].item())].cpu().numpy()
         oracle_ok = bool(got.size == want.size and (got == want).all())
-    del d_stream
 
-    # one row per rank: [round trip ok, compressed bytes, shard bytes, 1]; the last column counts the ranks
-    # the collective really saw
-    ok_flags = torch.tensor([int(roundtrip_equal and status == 0 and md5_in == md5_out), c_bytes, n, 1], dtype=torch.int64, device=ctl_dev)
-    if world > 1:
-        all_flags = [torch.zeros_like(ok_flags) for _ in range(world)]
-        dist.all_gather(all_flags, ok_flags)
-    else:
-        all_flags = [ok_flags]
-    all_ok = all(int(f[0].item()) == 1 for f in all_flags)
-    c_total = sum(int(f[1].item()) for f in all_flags)
-    total_bytes = sum(int(f[2].item()) for f in all_flags)
-    n_ranks_seen = sum(int(f[3].item()) for f in all_flags)
+    # one row per rank: [ok, compressed bytes, shard bytes, 1, encode us, decode us]; column 3 counts the ranks the
+    # collective really saw
+    ok = int(P["roundtrip_equal"] and P["status"] == 0 and P["md5_in"] == P["md5_out"] and side["decode_stream_roundtrip_equal"])
+    rows = gather_rows(dist, world, ctl_dev, [ok, c_bytes, n, 1, int(P["enc_ms"] * 1e3), int(P["dec_ms"] * 1e3)])
+    all_ok = all(r[0] == 1 for r in rows)
+    c_total = sum(r[1] for r in rows)
+    total_bytes = sum(r[2] for r in rows)
+    n_ranks_seen = sum(r[3] for r in rows)
 
     result = None
     if rank == 0:
         traffic = load_profiled_traffic(args.kind, n)
-        result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, elapsed, enc_avg, dec_avg, c_bytes, c_total,
-                                 all_ok, md5_in, md5_out, oracle_ok, status, traffic)
+        result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes, c_total,
+                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic)
+        result.update(side)
+        result["per_rank"] = {
+            "encode_ms_min": min(r[4] for r in rows) / 1e3, "encode_ms_max": max(r[4] for r in rows) / 1e3,
+            "decode_ms_min": min(r[5] for r in rows) / 1e3, "decode_ms_max": max(r[5] for r in rows) / 1e3,
+            "compressed_bytes": [r[1] for r in rows],
+        }
+
+    # ---- N > 1: the OTHER scaling mode in the same run (configs[3] strong: 8 GiB over N; configs[4] weak: 8 GiB each),
+    #      and the measurement behind "RCCL only if a gather is measurably cheaper than staged hipMemcpyAsync" ----
+    if world > 1 and not args.no_scaling_extras:
+        probe = gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl)
+        del d_stream, d_off, P
+        torch.cuda.empty_cache()
+        other = argparse.Namespace(**vars(args))
+        other.scaling = "strong" if args.scaling == "weak" else "weak"
+        Q = run_pass(other, H, dist, world, rank, dev, ctl_dev, max(3, args.steps // 4), 1)
+        q_rows = gather_rows(dist, world, ctl_dev, [int(Q["roundtrip_equal"] and Q["status"] == 0), Q["n"]])
+        if rank == 0:
+            q_total = sum(r[1] for r in q_rows)
+            q_steps = max(3, args.steps // 4)
+            result["gather_probe"] = probe
+            result["other_scaling"] = {
+                "scaling": other.scaling, "value": q_total * q_steps / Q["elapsed"] / 1e9, "unit": "GB/s",
+                "ms_per_step": Q["elapsed"] / q_steps * 1e3, "steps": q_steps, "total_bytes": q_total,
+                "encode_ms_rank0": Q["enc_ms"], "decode_ms_rank0": Q["dec_ms"], "roundtrip_equal": all(r[0] == 1 for r in q_rows),
+                "workload": (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPUs" if other.scaling == "strong"
+                             else f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU"),
+            }
+            all_ok = all_ok and result["other_scaling"]["roundtrip_equal"]
+        del Q
+    else:
+        del d_stream, d_off, P
+    torch.cuda.empty_cache()
 
     # ---- configs[1]: the 64 MiB stand-in for data/random_64m.dat, rank 0 only ----
     if rank == 0 and not args.no_small_config:

@@ -286,7 +286,7 @@ __device__ __forceinline__ void run_low(EncodeLds &lds, uint32_t lane, uint32_t 
 }
 
 __global__ void __launch_bounds__(4 * kLanes)
-encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets) {
+encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets, uint32_t *__restrict__ status) {
     __shared__ EncodeLds lds;
 
     const size_t group = xcd_contiguous_group(blockIdx.x, gridDim.x);
@@ -377,7 +377,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         if (live) {
             bool overflowed;
             coder.finish(len, overflowed);
-            if (overflowed) atomicOr(&g_status, GPUAR_STATUS_SLOT_OVERFLOW);
+            if (overflowed) atomicOr(status, GPUAR_STATUS_SLOT_OVERFLOW);
         }
     }
 }
@@ -446,6 +446,17 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
             "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
+#ifdef GPUAR_EXP_DSADD
+#define GPUAR_A_SHADOW_CARRIED \
+         /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
+            64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left, set by that symbol's step; v205: lx if lmc, \
+            the grandchild); no field can carry into its neighbour (counts stay below 2^14) */ \
+            "v_cndmask_b32 v205, 0, %[lx], %[lmc]\n\t" \
+            "ds_add_u64 %[oaddr], v[204:205]\n\t" \
+
+#define GPUAR_A_SHADOW_PLAIN \
+            "ds_add_u64 %[oaddr], v[204:205]\n\t" /* the increments of the previous symbol's low half, formed by its own step */
+#else
 #define GPUAR_A_SHADOW_CARRIED \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through (lbw, lcc as read) gets its \
             increments (lincb: +1 on the count, +0x10000 on the child if left; lx if lmc: the grandchild) and goes back */ \
@@ -456,12 +467,36 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 
 #define GPUAR_A_SHADOW_PLAIN \
             "ds_write_b64 %[oaddr], v[204:205]\n\t" /* the previous symbol's low half, rebuilt by its own step */
+#endif
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
             "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
             "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
 
+#ifdef GPUAR_EXP_DSADD
+#define GPUAR_MID_WRITEBACK \
+            "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
+            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
+         /* ---- the mid half takes its increments by one 64-bit LDS add in the shadow of read #2 */ \
+            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 v209, 0, %[t2], %[mc]\n\t" \
+            "ds_add_u64 %[am], v[208:209]\n\t"
+#else
+#define GPUAR_MID_WRITEBACK \
+            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
+            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
+         /* ---- the mid half updated and written back in the shadow of read #2 */ \
+            "v_add_u32 v208, %[bw], %[t3]\n\t" \
+            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
+            "v_add_u32 v209, %[cc], %[t2]\n\t" \
+            "ds_write_b64 %[am], v[208:209]\n\t"
+#endif
 #define GPUAR_BC_MID \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: v200 = aR | bR << 16, v201 = cRR | cRL << 16 (right half), v202 = a | bL << 16, v203 = cLR | cLL << 16 (left half) */ \
@@ -480,16 +515,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_sub_co_u32 %[t1], %[mc], %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
-            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
-            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
-         /* ---- the mid half updated and written back in the shadow of read #2 */ \
-            "v_add_u32 v208, %[bw], %[t3]\n\t" \
-            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
-            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
-            "v_add_u32 v209, %[cc], %[t2]\n\t" \
-            "ds_write_b64 %[am], v[208:209]\n\t"
+            GPUAR_MID_WRITEBACK
 
 #define GPUAR_BC_LOW \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid record's write-back, perhaps the stream reader's dword) */ \
@@ -542,6 +568,18 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
 
+#ifdef GPUAR_EXP_DSADD
+#define GPUAR_BC_TAIL_CARRIED \
+         /* ---- what the next step adds to this low half (in the shadow of its first read) */ \
+            "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
+            "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
+
+#define GPUAR_BC_TAIL_PLAIN \
+         /* ---- the increments of the low half -> v204:v205 (added by the next step) */ \
+            "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
+            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
+            "v_cndmask_b32 v205, 0, %[t2], %[lmc]\n\t"
+#else
 #define GPUAR_BC_TAIL_CARRIED \
          /* ---- what the next step needs to update this low half (it does so in the shadow of its first read) */ \
             "v_cndmask_b32 %[lincb], 1, %[k64k1], vcc\n\t" \
@@ -554,6 +592,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 %[t2], 0, %[t2], %[lmc]\n\t" \
             "v_add_u32 v205, %[lcc], %[t2]\n\t"
+#endif
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
@@ -593,6 +632,21 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, a, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx;
 
+#ifdef GPUAR_EXP_DSADD
+#define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
+    { \
+        GPUAR_STEP_LOCALS \
+        uint32_t lbw_, lcc_; \
+        unsigned long long lma_; \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
+            : GPUAR_STEP_OPERANDS_COMMON, \
+              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lx] "+v"(lx), [lma] "=&s"(lma_), [lmc] "+s"(lmc), "+v"(o0), "+v"(o1) \
+            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
+        NP_OUT = np; \
+    }
+#else
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
         GPUAR_STEP_LOCALS \
@@ -605,6 +659,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
+#endif
 
 #define GPUAR_DECODE_SYMBOL_PLAIN(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
@@ -629,7 +684,7 @@ constexpr uint32_t kDecodeLdsQuads = (kDecodeRecords + kRingPieces) * kLanes;
 // column of the workgroup's LDS (72 half-records, 512 bytes apart); `ring` = this lane's dword 0 in the 4 KiB
 // stream-ring region behind the records (16 dwords per lane, 256 bytes apart; the region is 4 KiB-aligned).
 __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const uint8_t *base, uint32_t pkt_off, uint32_t limit_off,
-                                            uint8_t *out, bool live) {
+                                            uint8_t *out, bool live, uint32_t *status) {
     DecoderLane<9> dec;
     dec.open(col, base, pkt_off, limit_off, live);
     const uint32_t len_max = wave_max(dec.ulen);
@@ -649,7 +704,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // boundary of LDS (the kernels' only __shared__ array is declared that way); anything else is a build error
     // that would decode garbage, so the wavefront flags every packet bad and decodes nothing instead
     if ((ring_lds & 0xF00u) != 0u) {
-        atomicOr(&g_status, GPUAR_STATUS_BAD_PACKET);
+        atomicOr(status, GPUAR_STATUS_BAD_PACKET);
         return;
     }
     register uint32_t o0 asm("v204");          // PLAIN: the low half of the previous symbol, updated, not yet written back
@@ -783,6 +838,22 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 
     // ---- blocks that every lane of the wavefront owns: uniform control flow, CARRIED variant ----
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
+#ifdef GPUAR_EXP_DSADD
+    {
+        // v204:v205 = the 64-bit increment the previous symbol's low half still has to take (added in the shadow of the
+        // next step's first read); nothing is owed yet: an add of zero to the half reset() named.
+        // (Initial values go through asm: a known constant would be spliced into the statements as an immediate.)
+        uint32_t lx;
+        unsigned long long lmc;
+        asm volatile("s_mov_b64 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=s"(lmc), "=v"(lx), "=v"(o0), "=v"(o1));
+        for (; i + 64u <= len_min; i += 64u) {
+            GPUAR_ROTATE_RECIPS
+            GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
+        }
+        // the increment still owed, completed the way the step does: v204:v205 then hold what is to be added
+        asm volatile("v_cndmask_b32 v205, 0, %[lx], %[lmc]" : "+v"(o0), "+v"(o1) : [lx] "v"(lx), [lmc] "s"(lmc));
+    }
+#else
     {
         uint32_t lbw, lcc, lincb, lx;
         unsigned long long lmc;
@@ -803,6 +874,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             : "=&v"(o0), "=&v"(o1), [lx] "+v"(lx)
             : [lbw] "v"(lbw), [lcc] "v"(lcc), [lincb] "v"(lincb), [lmc] "s"(lmc));
     }
+#endif
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
     //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
     for (; i + 64u <= len_max; i += 64u) {
@@ -820,8 +892,19 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     dec.next = (next64 >> 6) - skew16;
     dec.off = offr;
     dec.owed_bits = nbits;
+#ifdef GPUAR_EXP_DSADD
+    // the increment still owed goes in now; what the plain step is then handed as "owed" is a rewrite of that half with
+    // the values it holds (its write_back stores, it does not add)
+    asm volatile("ds_add_u64 %[oaddr], v[204:205]\n\ts_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1) : [oaddr] "v"(oaddr) : "memory");
+    dec.model.owed.at = oaddr - col_lds;
+    {
+        const Pair now = load64(col + dec.model.owed.at);
+        dec.model.owed.w0 = now.w[0], dec.model.owed.w1 = now.w[1];
+    }
+#else
     dec.model.owed.at = oaddr - col_lds;
     dec.model.owed.w0 = o0, dec.model.owed.w1 = o1;
+#endif
     dec.bad = dec.bad || bad_min < 0x80000000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
@@ -834,26 +917,32 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     }
     if (live) {
         dec.finish(out);
-        if (dec.bad) atomicOr(&g_status, GPUAR_STATUS_BAD_PACKET);
+        if (dec.bad) atomicOr(status, GPUAR_STATUS_BAD_PACKET);
     }
 }
 
 __global__ void __launch_bounds__(kLanes)
-decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint8_t *__restrict__ out) {
+decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, size_t n_bytes, uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];    // 40 KiB: 72 half-records x 64 lanes x 8 B, then 4 KiB of stream rings
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
     const bool live = packet < n_packets;
-    const uint8_t *group_slots = slots + static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);      // wave-uniform
-    decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, (lane + 1u) * kSlot,
-                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+    const size_t group_at = static_cast<size_t>(blockIdx.x) * (kLanes * kSlot);
+    const uint8_t *group_slots = slots + group_at;                                                // wave-uniform
+    // what may be read: the lane's slot, cut short where the caller's buffer ends (the last slot of garDecompressExecutor's
+    // `size` bytes may be a partial one, src/gpuar_kernel.cu:916-934)
+    const size_t group_left = n_bytes - group_at;
+    const uint32_t slot_end = (lane + 1u) * kSlot;
+    const uint32_t limit_off = group_left < slot_end ? static_cast<uint32_t>(group_left) : slot_end;
+    decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, limit_off,
+                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live, status);
 }
 
 // Decode from a back-to-back packet stream (the bytes after the 20-byte .gip
 // header): lane p starts at stream + offsets[p].
 __global__ void __launch_bounds__(kLanes)
 decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offsets,
-                     uint32_t n_packets, uint8_t *__restrict__ out) {
+                     uint32_t n_packets, uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     __shared__ __attribute__((aligned(4096))) uint4 lds[kDecodeLdsQuads];
     const uint32_t lane = threadIdx.x;
     const size_t packet = static_cast<size_t>(blockIdx.x) * kLanes + lane;
@@ -867,7 +956,7 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
     const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
     decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_stream, pkt_off, limit_off,
-                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live);
+                out + (live ? packet : 0) * static_cast<size_t>(kPacket), live, status);
 }
 
 // ---------------------------------------------------------------------------
@@ -1064,33 +1153,51 @@ int check_launch() {
     return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
 }
 
+// Where a launch reports SLOT_OVERFLOW / BAD_PACKET: the caller's own device word, or -- for callers that pass
+// none (the reference-named executors) -- the current device's fallback word, which gpuar_hip_status() reads.
+uint32_t *status_word(uint32_t *d_status) {
+    if (d_status) return d_status;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(gpuar::g_status)) != hipSuccess) return nullptr;
+    return static_cast<uint32_t *>(p);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t gpuar_hip_packet_count(size_t n_bytes) { return (n_bytes + GPUAR_PACKET_BYTES - 1) / GPUAR_PACKET_BYTES; }
 
-int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void *stream) {
+int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream) {
     if (n_bytes == 0) return GPUAR_OK;
     if (!d_in || !d_slots) return GPUAR_ERR_ARGUMENT;
-    if (!aligned16(d_in) || !aligned16(d_slots)) return GPUAR_ERR_ALIGNMENT;
+    if (!aligned16(d_in) || !aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_status) & 3u)) return GPUAR_ERR_ALIGNMENT;
+    uint32_t *status = status_word(d_status);
+    if (!status) return GPUAR_ERR_NO_DEVICE;
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t groups = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
     const uint32_t blocks = (groups + 7u) & ~7u;              // see xcd_contiguous_group
     gpuar::encode_kernel<<<blocks, 4 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
-        d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets));
+        d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
     return check_launch();
 }
 
-int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, void *stream) {
+// n_bytes: how much of d_slots may be read (n_packets * 8704, or less when the last slot is a partial one)
+static int launch_decode_slots(const uint8_t *d_slots, size_t n_packets, size_t n_bytes, uint8_t *d_out, uint32_t *d_status, void *stream) {
     if (n_packets == 0) return GPUAR_OK;
     if (!d_slots || !d_out || n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
-    if (!aligned16(d_slots) || !aligned16(d_out)) return GPUAR_ERR_ALIGNMENT;
+    if (!aligned16(d_slots) || !aligned16(d_out) || (reinterpret_cast<uintptr_t>(d_status) & 3u)) return GPUAR_ERR_ALIGNMENT;
+    uint32_t *status = status_word(d_status);
+    if (!status) return GPUAR_ERR_NO_DEVICE;
     const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
     gpuar::decode_slots_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
-        d_slots, static_cast<uint32_t>(n_packets), d_out);
+        d_slots, static_cast<uint32_t>(n_packets), n_bytes, d_out, status);
     return check_launch();
+}
+
+int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, uint32_t *d_status, void *stream) {
+    return launch_decode_slots(d_slots, n_packets, n_packets * static_cast<size_t>(GPUAR_SLOT_BYTES), d_out, d_status, stream);
 }
 
 int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_stream, uint64_t *d_offsets, void *stream) {
@@ -1115,13 +1222,15 @@ int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_strea
 }
 
 int gpuar_hip_decode_stream(const uint8_t *d_stream, const uint64_t *d_offsets, size_t n_packets,
-                            uint8_t *d_out, void *stream) {
+                            uint8_t *d_out, uint32_t *d_status, void *stream) {
     if (n_packets == 0) return GPUAR_OK;
     if (!d_stream || !d_offsets || !d_out || n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
-    if (!aligned16(d_out) || (reinterpret_cast<uintptr_t>(d_stream) & 3u)) return GPUAR_ERR_ALIGNMENT;
+    if (!aligned16(d_out) || (reinterpret_cast<uintptr_t>(d_stream) & 3u) || (reinterpret_cast<uintptr_t>(d_status) & 3u)) return GPUAR_ERR_ALIGNMENT;
+    uint32_t *status = status_word(d_status);
+    if (!status) return GPUAR_ERR_NO_DEVICE;
     const uint32_t blocks = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
     gpuar::decode_stream_kernel<<<blocks, gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
-        d_stream, d_offsets, static_cast<uint32_t>(n_packets), d_out);
+        d_stream, d_offsets, static_cast<uint32_t>(n_packets), d_out, status);
     return check_launch();
 }
 
@@ -1194,7 +1303,7 @@ void initConstantRange(void) {
 
 void garCompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks) {
     (void)numBlocks;
-    const int e = gpuar_hip_encode(source, size, destination, nullptr);
+    const int e = gpuar_hip_encode(source, size, destination, nullptr, nullptr);
     if (e != GPUAR_OK) {
         t_last_error = e;
         fprintf(stderr, "garCompressExecutor: %s\n", gpuar_hip_error_string(e));
@@ -1203,7 +1312,9 @@ void garCompressExecutor(const uint8_t *source, size_t size, uint8_t *destinatio
 
 void garDecompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks) {
     (void)numBlocks;
-    const int e = gpuar_hip_decode(source, size / GPUAR_SLOT_BYTES, destination, nullptr);
+    // the reference's kernel decodes every packet whose slot STARTS inside `size` (index * 8704 < size,
+    // src/gpuar_kernel.cu:916-934): a ceiling, not a floor
+    const int e = launch_decode_slots(source, (size + GPUAR_SLOT_BYTES - 1) / GPUAR_SLOT_BYTES, size, destination, nullptr, nullptr);
     if (e != GPUAR_OK) {
         t_last_error = e;
         fprintf(stderr, "garDecompressExecutor: %s\n", gpuar_hip_error_string(e));

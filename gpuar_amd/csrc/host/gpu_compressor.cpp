@@ -139,23 +139,27 @@ struct GPUCompressor::DeviceBuffers {
     uint64_t *d_offsets = nullptr;  // cap + 1
     uint8_t *h_plain = nullptr;     // pinned, cap * 8192
     uint8_t *h_stream = nullptr;    // pinned, cap * 8704 (+16)
-    uint64_t *h_offsets = nullptr;  // pinned, cap + 1
-    double kernel_ms = 0;           // summed over the chunks this lane handled
+    uint64_t *h_offsets = nullptr;  // pinned, cap + 2: the word behind the offsets receives this lane's status word
+    uint32_t *d_status = nullptr;   // this lane's own status word (device): its launches report here, nobody else's do
+    hipEvent_t epoch = nullptr;     // the device's common time base (owned by the device's first lane)
+    std::vector<std::pair<float, float>> busy;   // [begin, end) of every chunk's kernels, ms since `epoch`
 
     void allocate(int dev, size_t packets) {
         device = dev;
         cap = packets;
         hip_check(hipSetDevice(device), "hipSetDevice");
-        hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+        // non-blocking: a lane must never wait for another lane's copies or kernels through the NULL stream
+        hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipEventCreate(&t0), "hipEventCreate");
         hip_check(hipEventCreate(&t1), "hipEventCreate");
         hip_check(hipMalloc(reinterpret_cast<void **>(&d_plain), cap * kPacket), "hipMalloc");
         hip_check(hipMalloc(reinterpret_cast<void **>(&d_slots), cap * kSlot), "hipMalloc");
         hip_check(hipMalloc(reinterpret_cast<void **>(&d_stream), cap * kSlot + 16), "hipMalloc");
-        hip_check(hipMalloc(reinterpret_cast<void **>(&d_offsets), (cap + 1) * sizeof(uint64_t)), "hipMalloc");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_offsets), (cap + 2) * sizeof(uint64_t)), "hipMalloc");
+        d_status = reinterpret_cast<uint32_t *>(d_offsets + cap + 1);
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_plain), cap * kPacket, hipHostMallocDefault), "hipHostMalloc");
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_stream), cap * kSlot + 16, hipHostMallocDefault), "hipHostMalloc");
-        hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_offsets), (cap + 1) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_offsets), (cap + 2) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
     }
     void release() {
         if (!cap) return;
@@ -173,37 +177,49 @@ struct GPUCompressor::DeviceBuffers {
         cap = 0;
     }
 
-    // h_plain[0..n_plain) -> h_stream[0..n_stream), h_offsets[0..n_packets]; returns n_stream
-    size_t encodeChunk(size_t n_plain) {
+    // where this chunk's kernels ran on the device's clock
+    void noteBusy() {
+        float begin = 0, end = 0;
+        hip_check(hipEventElapsedTime(&begin, epoch, t0), "event");
+        hip_check(hipEventElapsedTime(&end, epoch, t1), "event");
+        busy.emplace_back(begin, end);
+    }
+
+    // h_plain[0..n_plain) -> h_stream[0..n_stream), h_offsets[0..n_packets]; returns n_stream and, through `flags`,
+    // what THIS chunk's launches reported (GPUAR_STATUS_*): the status word travels back with the offsets, on the
+    // lane's own stream -- no device-wide synchronisation, no flag shared with another lane
+    size_t encodeChunk(size_t n_plain, uint32_t &flags) {
         const size_t n_packets = (n_plain + kPacket - 1) / kPacket;
+        hip_check(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream), "memset");
         hip_check(hipMemcpyAsync(d_plain, h_plain, n_plain, hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipEventRecord(t0, stream), "event");
-        gpuar_check(gpuar_hip_encode(d_plain, n_plain, d_slots, stream), "gpuar_hip_encode");
+        gpuar_check(gpuar_hip_encode(d_plain, n_plain, d_slots, d_status, stream), "gpuar_hip_encode");
         gpuar_check(gpuar_hip_compact(d_slots, n_packets, d_stream, d_offsets, stream), "gpuar_hip_compact");
         hip_check(hipEventRecord(t1, stream), "event");
         hip_check(hipMemcpyAsync(h_offsets, d_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "D2H");
+        hip_check(hipMemcpyAsync(h_offsets + n_packets + 1, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
         const size_t n_stream = static_cast<size_t>(h_offsets[n_packets]);
+        flags = *reinterpret_cast<const uint32_t *>(h_offsets + n_packets + 1);
         hip_check(hipMemcpyAsync(h_stream, d_stream, n_stream, hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
-        float ms = 0;
-        hip_check(hipEventElapsedTime(&ms, t0, t1), "event");
-        kernel_ms += ms;
+        noteBusy();
         return n_stream;
     }
 
-    // h_stream[0..n_stream) with h_offsets[0..n_packets] -> h_plain[0..n_packets*8192)
-    void decodeChunk(size_t n_stream, size_t n_packets) {
+    // h_stream[0..n_stream) with h_offsets[0..n_packets] -> h_plain[0..n_packets*8192); returns this chunk's status flags
+    uint32_t decodeChunk(size_t n_stream, size_t n_packets) {
+        hip_check(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream), "memset");
         hip_check(hipMemcpyAsync(d_stream, h_stream, n_stream, hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipMemcpyAsync(d_offsets, h_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipEventRecord(t0, stream), "event");
-        gpuar_check(gpuar_hip_decode_stream(d_stream, d_offsets, n_packets, d_plain, stream), "gpuar_hip_decode_stream");
+        gpuar_check(gpuar_hip_decode_stream(d_stream, d_offsets, n_packets, d_plain, d_status, stream), "gpuar_hip_decode_stream");
         hip_check(hipEventRecord(t1, stream), "event");
         hip_check(hipMemcpyAsync(h_plain, d_plain, n_packets * kPacket, hipMemcpyDeviceToHost, stream), "D2H");
+        hip_check(hipMemcpyAsync(h_offsets + n_packets + 1, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
-        float ms = 0;
-        hip_check(hipEventElapsedTime(&ms, t0, t1), "event");
-        kernel_ms += ms;
+        noteBusy();
+        return *reinterpret_cast<const uint32_t *>(h_offsets + n_packets + 1);
     }
 };
 
@@ -223,6 +239,12 @@ void GPUCompressor::releaseBuffers() {
         delete b;
     }
     buffers.clear();
+    for (size_t g = 0; g < epochs.size(); ++g)
+        if (epochs[g]) {
+            (void)hipSetDevice(devices[g]);
+            (void)hipEventDestroy(static_cast<hipEvent_t>(epochs[g]));
+        }
+    epochs.clear();
 }
 
 // kLanesPerDevice buffer sets per device, sized for the job at hand: a file of `total_packets` is cut
@@ -314,13 +336,14 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                     if (c >= n_chunks || failure.stop) break;
                     if (!b.cap) b.allocate(b.device, chunkPackets);
                     hip_check(hipSetDevice(b.device), "hipSetDevice");
+                    b.epoch = static_cast<hipEvent_t>(epochOf(g));
                     const uint64_t at = static_cast<uint64_t>(c) * chunk_bytes;
                     const size_t n_plain = static_cast<size_t>(std::min<uint64_t>(chunk_bytes, info.uncompressedFileSize - at));
                     sliced_io<false>(in_fd, b.h_plain, n_plain, at, "Read input file failed");
-                    const size_t n_stream = b.encodeChunk(n_plain);
                     uint32_t flags = 0;
-                    gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
-                    if (flags & GPUAR_STATUS_SLOT_OVERFLOW) throw std::runtime_error("a packet outgrew its 8704-byte slot");
+                    const size_t n_stream = b.encodeChunk(n_plain, flags);
+                    if (flags & GPUAR_STATUS_SLOT_OVERFLOW)
+                        throw std::runtime_error("a packet outgrew its 8704-byte slot (input bytes " + std::to_string(at) + " .. " + std::to_string(at + n_plain) + ")");
                     const size_t n_packets = (n_plain + kPacket - 1) / kPacket;
                     if (writeIndex) {
                         chunk_clens[c].resize(n_packets);
@@ -361,16 +384,51 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
     return info;
 }
 
-// "Compute time" = kernels + their sync, as src/gpu_compressor.cpp:184-194 -- with several lanes and
-// devices working at once, the busiest device's total; the rest of the wall time is I/O.
+// "Compute time" = kernels + their sync, as src/gpu_compressor.cpp:184-194.  The lanes of a device run their
+// kernels at the same time, so their spans overlap (and each span includes time queued behind another lane's
+// kernels): what is reported is the time the device had at least one chunk's kernels in flight -- the UNION of
+// the lanes' [first kernel submitted, last kernel done) intervals on the device's own clock -- of the busiest
+// device; the rest of the wall time is I/O.
 void GPUCompressor::finishTimes(CompressionInfo &info) {
-    std::vector<double> per_device(devices.size(), 0.0);
-    for (size_t l = 0; l < buffers.size(); ++l) {
-        per_device[l / kLanesPerDevice] += buffers[l]->kernel_ms;
-        buffers[l]->kernel_ms = 0;
+    double busiest = 0;
+    for (size_t g = 0; g < devices.size(); ++g) {
+        std::vector<std::pair<float, float>> spans;
+        for (size_t l = g * kLanesPerDevice; l < (g + 1) * kLanesPerDevice && l < buffers.size(); ++l) {
+            spans.insert(spans.end(), buffers[l]->busy.begin(), buffers[l]->busy.end());
+            buffers[l]->busy.clear();
+        }
+        std::sort(spans.begin(), spans.end());
+        double total = 0;
+        float open_begin = 0, open_end = -1;
+        for (const auto &sp : spans) {
+            if (open_end < open_begin || sp.first > open_end) {      // a gap: close the run so far
+                if (open_end >= open_begin) total += open_end - open_begin;
+                open_begin = sp.first;
+                open_end = sp.second;
+            } else {
+                open_end = std::max(open_end, sp.second);
+            }
+        }
+        if (open_end >= open_begin) total += open_end - open_begin;
+        busiest = std::max(busiest, total);
     }
-    info.processTime = *std::max_element(per_device.begin(), per_device.end());
+    info.processTime = busiest;
     info.ioTime = std::max(0.0, io_timer.value() - info.processTime);
+}
+
+// One event per device that every lane of the device measures its kernel intervals against.
+void *GPUCompressor::epochOf(size_t g) {
+    std::lock_guard<std::mutex> hold(epochLock);
+    if (epochs.size() < devices.size()) epochs.resize(devices.size(), nullptr);
+    if (!epochs[g]) {
+        hipEvent_t e = nullptr;
+        hip_check(hipSetDevice(devices[g]), "hipSetDevice");
+        hip_check(hipEventCreate(&e), "hipEventCreate");
+        hip_check(hipEventRecord(e, nullptr), "event");
+        hip_check(hipEventSynchronize(e), "event");
+        epochs[g] = e;
+    }
+    return epochs[g];
 }
 
 namespace {
@@ -427,10 +485,16 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         if (std::fread(header.getData(), FileHeader::HEADER_LENGTH, 1, openFile) != 1 || !header.checkHeaderVersion())
             throw std::runtime_error("Incorrect file format");
         info = header.getInfo(fileSize);
-        // every packet but the last holds 8192 bytes; a packet is at least 4 bytes long, which bounds a lying header
-        ensureBuffers(std::min((info.uncompressedFileSize + kPacket - 1) / kPacket, fileSize / GPUAR_PACKET_HEADER_BYTES + 1));
         const size_t G = devices.size();
         const uint64_t stream_end = streamEnd(info, fileSize);
+        // How many packets to size the chunks for.  Every packet but the last holds 8192 bytes, so the header's
+        // uncompressed size says; but a file written by the reference keeps only the low 32 bits of that size
+        // (src/file_header.hpp:31-36) and a header can lie, so the count is bounded from below by the stream itself
+        // (a packet is at most 8704 bytes long) and from above by it as well (at least 4).
+        const size_t stream_bytes = static_cast<size_t>(stream_end - FileHeader::HEADER_LENGTH);
+        const size_t by_header = (info.uncompressedFileSize + kPacket - 1) / kPacket;
+        const size_t at_least = (stream_bytes + kSlot - 1) / kSlot, at_most = stream_bytes / GPUAR_PACKET_HEADER_BYTES + 1;
+        ensureBuffers(std::min(std::max(by_header, at_least), at_most));
         const int in_fd = fileno(openFile), out_fd = fileno(saveFile);
         // packet lengths from the index trailer when the file has one (packet_index.hpp)
         std::vector<uint16_t> index;
@@ -496,6 +560,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                         if (failure.stop || !map.get(c, chunk)) break;
                         if (!b.cap) b.allocate(b.device, chunkPackets);
                         hip_check(hipSetDevice(b.device), "hipSetDevice");
+                        b.epoch = static_cast<hipEvent_t>(epochOf(g));
                         const size_t n_stream = static_cast<size_t>(chunk.end - chunk.begin);
                         sliced_io<false>(in_fd, b.h_stream, n_stream, chunk.begin, "Invalid file length");
                         // packet offsets inside the chunk, and what every packet says it holds (u16 at +2): all but the
@@ -519,10 +584,9 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                         if (off != n_stream) throw std::runtime_error("Invalid file length");
                         b.h_offsets[chunk.n_packets] = off;
                         const uint64_t out_at = place.take(c, produced);
-                        b.decodeChunk(n_stream, chunk.n_packets);
-                        uint32_t flags = 0;
-                        gpuar_check(gpuar_hip_status(&flags), "gpuar_hip_status");
-                        if (flags & GPUAR_STATUS_BAD_PACKET) throw std::runtime_error("Incorrect file format");
+                        const uint32_t flags = b.decodeChunk(n_stream, chunk.n_packets);
+                        if (flags & GPUAR_STATUS_BAD_PACKET)
+                            throw std::runtime_error("Incorrect file format (malformed packet between file offsets " + std::to_string(chunk.begin) + " and " + std::to_string(chunk.end) + ")");
                         if (all_full) {
                             sliced_io<true>(out_fd, b.h_plain, static_cast<size_t>(produced), out_at, "Write uncompressed data to output file failed");
                         } else {             // short packets inside the chunk: one write per packet

@@ -7,6 +7,7 @@
 // per-packet memcpys on one thread (src/gpu_compressor.cpp:134-171).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "compressor.hpp"
@@ -41,12 +42,15 @@ class GPUCompressor : public Compressor {
     std::vector<DeviceBuffers *> buffers;      // one per lane, device-major
     size_t batchPackets = 8192;
     size_t chunkPackets = 0;                   // chunk size of the job the buffers were set up for
+    std::vector<void *> epochs;                // one hipEvent_t per device: the time base of its lanes' kernel intervals
+    std::mutex epochLock;
 
     void releaseBuffers();
     void ensureBuffers(size_t total_packets);
     template <typename Work>
     void runLanes(Work &&work);
     void finishTimes(CompressionInfo &info);
+    void *epochOf(size_t device_index);
 };
 
 }  // namespace gip

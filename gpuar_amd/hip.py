@@ -51,13 +51,13 @@ def load() -> C.CDLL:
     lib.gpuar_hip_packet_count.restype = sz
     lib.gpuar_hip_packet_count.argtypes = [sz]
     lib.gpuar_hip_encode.restype = C.c_int
-    lib.gpuar_hip_encode.argtypes = [vp, sz, vp, vp]
+    lib.gpuar_hip_encode.argtypes = [vp, sz, vp, vp, vp]
     lib.gpuar_hip_decode.restype = C.c_int
-    lib.gpuar_hip_decode.argtypes = [vp, sz, vp, vp]
+    lib.gpuar_hip_decode.argtypes = [vp, sz, vp, vp, vp]
     lib.gpuar_hip_compact.restype = C.c_int
     lib.gpuar_hip_compact.argtypes = [vp, sz, vp, vp, vp]
     lib.gpuar_hip_decode_stream.restype = C.c_int
-    lib.gpuar_hip_decode_stream.argtypes = [vp, vp, sz, vp, vp]
+    lib.gpuar_hip_decode_stream.argtypes = [vp, vp, sz, vp, vp, vp]
     lib.gpuar_hip_status.restype = C.c_int
     lib.gpuar_hip_status.argtypes = [C.POINTER(C.c_uint32)]
     lib.gpuar_hip_last_error.restype = C.c_int
@@ -93,8 +93,19 @@ def _require_cuda_u8(t, name):
         raise GpuarError(f"{name} must be a contiguous uint8 CUDA tensor")
 
 
-def encode(d_in, d_slots=None, stream=None):
-    """Encode the bytes of `d_in` into 8704-byte packet slots (garCompress layout)."""
+def _status_ptr(d_status):
+    """Device address of a caller-owned status word (a 1-element int32/uint32 CUDA tensor), or None."""
+    if d_status is None:
+        return None
+    import torch
+    if not (isinstance(d_status, torch.Tensor) and d_status.is_cuda and d_status.element_size() == 4 and d_status.numel() >= 1):
+        raise GpuarError("d_status must be a CUDA tensor of one 32-bit word")
+    return d_status.data_ptr()
+
+
+def encode(d_in, d_slots=None, stream=None, d_status=None):
+    """Encode the bytes of `d_in` into 8704-byte packet slots (garCompress layout).  `d_status`: this launch's
+    own status word (a zeroed 1-element int32 CUDA tensor); None = the device's fallback word (status())."""
     import torch
     _require_cuda_u8(d_in, "d_in")
     n = d_in.numel()
@@ -104,11 +115,11 @@ def encode(d_in, d_slots=None, stream=None):
     _require_cuda_u8(d_slots, "d_slots")
     if d_slots.numel() < npk * SLOT:
         raise GpuarError("d_slots too small")
-    _check(load().gpuar_hip_encode(d_in.data_ptr(), n, d_slots.data_ptr(), _stream_handle(stream)), "gpuar_hip_encode")
+    _check(load().gpuar_hip_encode(d_in.data_ptr(), n, d_slots.data_ptr(), _status_ptr(d_status), _stream_handle(stream)), "gpuar_hip_encode")
     return d_slots
 
 
-def decode(d_slots, n_packets: int, d_out=None, stream=None):
+def decode(d_slots, n_packets: int, d_out=None, stream=None, d_status=None):
     """Decode `n_packets` slots into n_packets*8192 output bytes."""
     import torch
     _require_cuda_u8(d_slots, "d_slots")
@@ -119,7 +130,7 @@ def decode(d_slots, n_packets: int, d_out=None, stream=None):
     _require_cuda_u8(d_out, "d_out")
     if d_out.numel() < n_packets * PACKET:
         raise GpuarError("d_out too small")
-    _check(load().gpuar_hip_decode(d_slots.data_ptr(), n_packets, d_out.data_ptr(), _stream_handle(stream)), "gpuar_hip_decode")
+    _check(load().gpuar_hip_decode(d_slots.data_ptr(), n_packets, d_out.data_ptr(), _status_ptr(d_status), _stream_handle(stream)), "gpuar_hip_decode")
     return d_out
 
 
@@ -136,18 +147,19 @@ def compact(d_slots, n_packets: int, d_stream=None, d_offsets=None, stream=None)
     return d_stream, d_offsets
 
 
-def decode_stream(d_stream, d_offsets, n_packets: int, d_out=None, stream=None):
+def decode_stream(d_stream, d_offsets, n_packets: int, d_out=None, stream=None, d_status=None):
     import torch
     _require_cuda_u8(d_stream, "d_stream")
     if d_out is None:
         d_out = torch.empty(max(n_packets, 1) * PACKET, dtype=torch.uint8, device=d_stream.device)
     _check(load().gpuar_hip_decode_stream(d_stream.data_ptr(), d_offsets.data_ptr(), n_packets, d_out.data_ptr(),
-                                          _stream_handle(stream)), "gpuar_hip_decode_stream")
+                                          _status_ptr(d_status), _stream_handle(stream)), "gpuar_hip_decode_stream")
     return d_out
 
 
 def status() -> int:
-    """Reads and clears the device status word (synchronises)."""
+    """Reads and clears the device's FALLBACK status word -- what launches without a d_status of their own
+    reported (synchronises the device)."""
     flags = C.c_uint32(0)
     _check(load().gpuar_hip_status(C.byref(flags)), "gpuar_hip_status")
     return int(flags.value)

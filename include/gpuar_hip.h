@@ -11,8 +11,11 @@
  * Plain pointers and sizes only.  All `d_*` / `source` / `destination`
  * pointers are DEVICE pointers owned by the caller (hipMalloc, or any
  * allocator that yields HIP device memory, e.g. a torch CUDA tensor).
- * Nothing here allocates device memory or keeps state between calls (except
- * the per-device status word), and nothing throws across the boundary.
+ * Nothing here allocates device memory, and nothing throws across the boundary.
+ * State kept between calls, all of it per device and none of it affecting
+ * results: a fallback status word (used only by launches that were given no
+ * status word of their own, i.e. the reference-named executors) and an arrival
+ * counter per compute unit the encoder uses to place its wavefronts.
  *
  * Packet geometry (reference: src/gpu.h:8-14):
  *   input  is cut into 8192-byte packets, packet p = bytes [p*8192, ...)
@@ -44,7 +47,8 @@ extern "C" {
 #define GPUAR_ERR_ARGUMENT      (-2)  /* null pointer / size out of range              */
 #define GPUAR_ERR_NO_DEVICE     (-3)  /* no HIP device visible                         */
 
-/* Bits of the device status word (gpuar_hip_status). */
+/* Bits a launch ORs into its status word (the caller's `d_status`, or the
+ * device's fallback word that gpuar_hip_status reads). */
 #define GPUAR_STATUS_SLOT_OVERFLOW  0x1u /* a packet outgrew its 8704-byte slot; its slot is truncated
                                             (the reference would write past the slot, SURVEY.md s.7 risk 3) */
 #define GPUAR_STATUS_BAD_PACKET     0x2u /* decode met a malformed packet (ulen > 8192, clen < 4, or a code
@@ -72,8 +76,9 @@ void initConstantRange(void);
 void garCompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks);
 
 /* Replaces garDecompressExecutor (src/gpuar_kernel.cu:946-954): `size` is
- * numPackets*8704 (src/gpu_compressor.cpp:357); slot p decodes to
- * destination + p*8192. */
+ * numPackets*8704 (src/gpu_compressor.cpp:357); every slot that STARTS inside
+ * `size` is decoded (index*8704 < size, src/gpuar_kernel.cu:916-934) and nothing
+ * at or beyond source + size is read; slot p decodes to destination + p*8192. */
 void garDecompressExecutor(const uint8_t *source, size_t size, uint8_t *destination, uint32_t numBlocks);
 
 /* ------------------------------------------------------------------------
@@ -84,13 +89,20 @@ void garDecompressExecutor(const uint8_t *source, size_t size, uint8_t *destinat
 /* Number of packets / slots for an input of n_bytes. */
 size_t gpuar_hip_packet_count(size_t n_bytes);
 
+/* `d_status` (encode, decode, decode_stream): a caller-owned 32-bit DEVICE word
+ * (4-byte aligned) that this launch -- and only this launch -- ORs its
+ * GPUAR_STATUS_* bits into; the caller zeroes it and copies it back on the same
+ * stream, so concurrent launches on other streams never share a flag and no
+ * device-wide synchronisation is needed.  NULL: the bits go to the device's
+ * fallback word instead (gpuar_hip_status). */
+
 /* Encode n_bytes at d_in (16-byte aligned) into packet slots at d_slots
  * (16-byte aligned, gpuar_hip_packet_count(n_bytes)*8704 bytes). */
-int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, void *stream);
+int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream);
 
 /* Decode n_packets slots at d_slots into d_out (n_packets*8192 bytes; the
  * last packet writes only its ulen bytes). */
-int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, void *stream);
+int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, uint32_t *d_status, void *stream);
 
 /* Device-side compaction (what the reference does with one 8704-byte D2H copy
  * and one fwrite per packet, src/gpu_compressor.cpp:138,161-168):
@@ -109,10 +121,12 @@ int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_strea
  * walking `off += clen`, src/gpu_compressor.cpp:299-312, or keeps the array
  * gpuar_hip_compact produced). */
 int gpuar_hip_decode_stream(const uint8_t *d_stream, const uint64_t *d_offsets, size_t n_packets,
-                            uint8_t *d_out, void *stream);
+                            uint8_t *d_out, uint32_t *d_status, void *stream);
 
-/* Reads and clears the device status word of the current device
- * (synchronises the device). */
+/* Reads and clears the FALLBACK status word of the current device: what
+ * launches without a `d_status` of their own reported (the reference-named
+ * executors above).  Synchronises the whole device -- meant for that
+ * single-stream legacy use, not for pipelines (pass `d_status` there). */
 int gpuar_hip_status(uint32_t *flags);
 
 /* Last error recorded by a void-returning reference-named entry point on this

@@ -43,6 +43,6 @@ sed -e '453,460d' -e '894,954d' "$ref/src/gpuar_kernel.cu" \
 g++ $flags -c "$here/ref_driver.cpp" -o "$out/ref_driver.o"
 # -Bsymbolic: the reference defines extern "C" read()/write() helpers
 # (src/gpuar_kernel.cu:18-74); bind them inside the library so libc's do not win.
-g++ -shared -Wl,-Bsymbolic -o "$out/libgpuar_ref.so" "$out/ref_codec.o" "$out/ref_driver.o"
+g++ -shared -Wl,-Bsymbolic -o "$out/libgpuar_ref.so" "$out/ref_codec.o" "$out/ref_driver.o" -lpthread
 rm -f "$out/ref_codec.o" "$out/ref_driver.o"
 echo "build_ref: built $out/libgpuar_ref.so"

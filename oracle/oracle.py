@@ -75,6 +75,20 @@ class _Codec:
         n = self._enc_stream(_ptr(src), a.size, _ptr(out))
         return out[:n].copy()
 
+    # -- the same with the packets fanned out over `threads` host threads (bench.py's all-cores CPU row).
+    #    Generic version: one contiguous packet range per Python thread, each ONE long C call (ctypes releases the GIL).
+    def encode_stream_mt(self, data, threads: int) -> np.ndarray:
+        from concurrent.futures import ThreadPoolExecutor
+        a = np.ascontiguousarray(data)
+        npk = (a.size + PACKET_IN - 1) // PACKET_IN
+        per = (npk + threads - 1) // threads * PACKET_IN
+        parts = [a[t * per:(t + 1) * per] for t in range(threads) if t * per < a.size]
+        with ThreadPoolExecutor(len(parts)) as pool:
+            return np.concatenate(list(pool.map(self.encode_stream, parts)))
+
+    def decode_stream_mt(self, stream, n_out: int, threads: int) -> np.ndarray:
+        return self.decode_stream(stream, n_out)              # (the port has no threaded decoder: single thread)
+
 
 class PortOracle(_Codec):
     kind = "port"
@@ -137,6 +151,34 @@ class ReferenceOracle(_Codec):
         lib.ref_decode_packet.argtypes = [_u8p, C.c_size_t, _u8p]
         lib.ref_decode_stream.restype = C.c_size_t
         lib.ref_decode_stream.argtypes = [_u8p, C.c_size_t, _u8p]
+        self._have_mt = hasattr(lib, "ref_encode_stream_mt")
+        if self._have_mt:
+            lib.ref_encode_stream_mt.restype = C.c_size_t
+            lib.ref_encode_stream_mt.argtypes = [_u8p, C.c_size_t, _u8p, C.c_uint]
+            lib.ref_decode_stream_mt.restype = C.c_size_t
+            lib.ref_decode_stream_mt.argtypes = [_u8p, C.c_size_t, _u8p, C.c_uint]
+
+    def encode_stream_mt(self, data, threads: int) -> np.ndarray:
+        """Native threads (oracle/ref_driver.cpp): one contiguous packet range per thread."""
+        if not self._have_mt:
+            return super().encode_stream_mt(data, threads)
+        a = np.ascontiguousarray(data)
+        npk = (a.size + PACKET_IN - 1) // PACKET_IN
+        out = np.empty(npk * PACKET_SLOT + 64, dtype=np.uint8)
+        src = np.zeros(a.size + 32, dtype=np.uint8)
+        src[:a.size] = a
+        n = self._lib.ref_encode_stream_mt(_ptr(src), a.size, _ptr(out), threads)
+        return out[:n]
+
+    def decode_stream_mt(self, stream, n_out: int, threads: int) -> np.ndarray:
+        if not self._have_mt:
+            return self.decode_stream(stream, n_out)
+        a = np.ascontiguousarray(stream)
+        out = np.zeros(n_out + PACKET_IN + 64, dtype=np.uint8)
+        n = self._lib.ref_decode_stream_mt(_ptr(a), a.size, _ptr(out), threads)
+        if n == C.c_size_t(-1).value:
+            raise ValueError("malformed packet stream")
+        return out[:n]
 
     def decode_packet(self, pkt: bytes) -> bytes:
         a = np.frombuffer(pkt, dtype=np.uint8).copy()

@@ -13,6 +13,8 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <thread>
+#include <vector>
 #include "gpuar.h"   // the reference header, found via -I/root/reference/src
 
 namespace {
@@ -75,6 +77,62 @@ size_t ref_decode_stream(const uint8_t *stream, size_t n_stream, uint8_t *out)
         off += clen;
     }
     return produced;
+}
+
+// ---- the same two loops with the packets fanned out over native threads, one contiguous packet range per
+// thread (packets are independent: every one starts from a fresh model).  bench.py's all-cores CPU row.
+size_t ref_encode_stream_mt(const uint8_t *in, size_t n_bytes, uint8_t *out, unsigned threads)
+{
+    const size_t n_packets = (n_bytes + kIn - 1) / kIn;
+    if (threads < 1) threads = 1;
+    if (threads > n_packets) threads = n_packets ? (unsigned)n_packets : 1;
+    const size_t per = (n_packets + threads - 1) / threads;
+    std::vector<std::vector<uint8_t> > seg(threads);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const size_t p0 = t * per, p1 = (t + 1) * per < n_packets ? (t + 1) * per : n_packets;
+            if (p0 >= p1) return;
+            const size_t b0 = p0 * kIn, b1 = p1 * kIn < n_bytes ? p1 * kIn : n_bytes;
+            seg[t].resize((p1 - p0) * kSlot + 64);
+            seg[t].resize(ref_encode_stream(in + b0, b1 - b0, seg[t].data()));
+        });
+    for (auto &th : pool) th.join();
+    size_t total = 0;
+    for (unsigned t = 0; t < threads; ++t) {
+        memcpy(out + total, seg[t].data(), seg[t].size());
+        total += seg[t].size();
+    }
+    return total;
+}
+
+size_t ref_decode_stream_mt(const uint8_t *stream, size_t n_stream, uint8_t *out, unsigned threads)
+{
+    std::vector<size_t> at;                                  // the header walk (`off += clen`), serial and cheap
+    size_t off = 0;
+    while (off + 4 <= n_stream) {
+        const size_t clen = (size_t)stream[off] | ((size_t)stream[off + 1] << 8);
+        if (clen < 4 || clen > n_stream - off) return (size_t)-1;
+        at.push_back(off);
+        off += clen;
+    }
+    at.push_back(off);
+    const size_t n_packets = at.size() - 1;
+    if (threads < 1) threads = 1;
+    if (threads > n_packets) threads = n_packets ? (unsigned)n_packets : 1;
+    const size_t per = (n_packets + threads - 1) / threads;
+    std::vector<size_t> produced(threads, 0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const size_t p0 = t * per, p1 = (t + 1) * per < n_packets ? (t + 1) * per : n_packets;
+            // every packet but the stream's last holds 8192 bytes: packet p decodes to out + p * 8192
+            for (size_t p = p0; p < p1; ++p) produced[t] += ref_decode_packet(stream + at[p], at[p + 1] - at[p], out + p * kIn);
+        });
+    for (auto &th : pool) th.join();
+    size_t total = 0;
+    for (size_t v : produced) total += v;
+    return total;
 }
 
 // ---- model-explicit variants: the caller owns the model state, exactly as the

@@ -195,3 +195,34 @@ def test_gpu_cli_decodes_files_with_the_references_uninitialised_header_bytes(tm
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == data.tobytes()
     assert f"Uncompressed file size {data.size} bytes" in r.stdout
+
+
+def test_gpu_cli_names_the_chunk_of_a_corrupted_packet(tmp_path):
+    """A multi-chunk .gip with one damaged packet: the lane that decodes that chunk reports it through its own
+    status word (no device-wide flag shared between the three lanes of a device), the CLI fails with the
+    reference's message and says which chunk it was -- and the same file with the damage undone decodes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, gip, back = tmp_path / "in.dat", tmp_path / "out.gip", tmp_path / "back.dat"
+    data = synth.text(21, 64 * 30 * 8192 + 777)              # 30 chunks of 64 packets, last one ragged
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={gip}", "--batch=64").returncode == 0
+    blob = bytearray(open(gip, "rb").read())
+    # walk to packet 64 * 17 + 5 (chunk 17 at --batch=64) and claim an impossible ulen
+    at = 20
+    for _ in range(64 * 17 + 5):
+        at += blob[at] | (blob[at + 1] << 8)
+    chunk_begin = 20
+    for _ in range(64 * 17):
+        chunk_begin += blob[chunk_begin] | (blob[chunk_begin + 1] << 8)
+    saved = bytes(blob[at + 2:at + 4])
+    blob[at + 2:at + 4] = b"\xff\xff"
+    open(gip, "wb").write(blob)
+    for attempt in range(3):                                  # lanes race differently every time: always chunk 17
+        r = run("d", f"--in={gip}", f"--out={back}", "--batch=64")
+        assert r.returncode == 1 and "Incorrect file format" in r.stderr, r.stderr
+        assert f"between file offsets {chunk_begin} and" in r.stderr, r.stderr
+    blob[at + 2:at + 4] = saved
+    open(gip, "wb").write(blob)
+    assert run("d", f"--in={gip}", f"--out={back}", "--batch=64").returncode == 0
+    assert open(back, "rb").read() == data.tobytes()

@@ -157,9 +157,9 @@ def test_reference_named_executors(H):
 def test_argument_errors(H):
     lib = H.load()
     buf = torch.zeros(8704 * 2 + 64, dtype=torch.uint8, device="cuda")
-    assert lib.gpuar_hip_encode(buf.data_ptr() + 1, 100, buf.data_ptr(), None) == -1      # misaligned input
-    assert lib.gpuar_hip_encode(None, 100, buf.data_ptr(), None) == -2
-    assert lib.gpuar_hip_encode(buf.data_ptr(), 0, buf.data_ptr(), None) == 0              # empty input: nothing to do
+    assert lib.gpuar_hip_encode(buf.data_ptr() + 1, 100, buf.data_ptr(), None, None) == -1      # misaligned input
+    assert lib.gpuar_hip_encode(None, 100, buf.data_ptr(), None, None) == -2
+    assert lib.gpuar_hip_encode(buf.data_ptr(), 0, buf.data_ptr(), None, None) == 0              # empty input: nothing to do
     lib.garCompressExecutor(buf.data_ptr() + 1, 100, buf.data_ptr(), 1)
     assert lib.gpuar_hip_last_error() == -1 and lib.gpuar_hip_last_error() == 0
 
@@ -178,6 +178,107 @@ def test_malformed_packets_are_flagged_not_fatal(H):
     assert flags & H.STATUS_BAD_PACKET
     assert bool((d_out[npk * 8192:] == 0xA5).all())
     assert H.status() == 0                        # status is read-and-clear
+
+
+def test_status_word_per_launch(H):
+    """Per-call status (include/gpuar_hip.h `d_status`): two decode launches in flight on two streams, one over
+    malformed packets and one over good ones, each with its own device word -- the flag lands in the word of the
+    launch that met the bad packet, the other stays 0, and the device's fallback word is not touched."""
+    assert H.status() == 0
+    n = 200 * 8192
+    data = synth.zipf(9, n)
+    npk = H.packet_count(n)
+    good = H.encode(torch.from_numpy(data).cuda())
+    bad = good.clone()
+    view = bad.view(npk, 8704)
+    view[7, 2] = 0xFF                       # ulen = 0xFFxx > 8192
+    view[7, 3] = 0xFF
+    view[150, 4:200] = 0xFF                 # a code value no symbol owns somewhere down the packet, most likely
+    words = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    out_bad = H.decode(bad, npk, stream=s1, d_status=words[0:1])
+    out_good = H.decode(good, npk, stream=s2, d_status=words[1:2])
+    d_stream, d_off = H.compact(good, npk)
+    out_stream = H.decode_stream(d_stream, d_off, npk, d_status=words[2:3])
+    H.encode(torch.from_numpy(data).cuda(), d_status=words[3:4])
+    torch.cuda.synchronize()
+    w = words.cpu().numpy()
+    assert w[0] & H.STATUS_BAD_PACKET and w[1] == 0 and w[2] == 0 and w[3] == 0
+    assert H.status() == 0                                   # nothing went to the fallback word
+    assert np.array_equal(out_good[:n].cpu().numpy(), data) and np.array_equal(out_stream[:n].cpu().numpy(), data)
+    # every packet but the two damaged ones still decodes to its bytes (a bad packet garbles only its own 8192)
+    ok = np.ones(npk, dtype=bool)
+    ok[[7, 150]] = False
+    got = out_bad.cpu().numpy().reshape(npk, 8192)
+    assert np.array_equal(got[ok], data.reshape(npk, 8192)[ok])
+    assert lib_misaligned_status(H) == -1
+
+
+def lib_misaligned_status(H):
+    buf = torch.zeros(8704 + 64, dtype=torch.uint8, device="cuda")
+    return H.load().gpuar_hip_decode(buf.data_ptr(), 1, buf.data_ptr(), buf.data_ptr() + 2, None)
+
+
+def test_executor_decodes_every_slot_that_starts_inside_size(H):
+    """garDecompressExecutor's `size` (src/gpuar_kernel.cu:916-934): a slot is decoded when it STARTS inside
+    `size` -- the last one may be cut short right behind its packet -- and nothing at or behind source + size is
+    read: the buffer ends exactly there, with a canary page of 0xEE behind it that must not influence anything."""
+    lib = H.load()
+    n = 66 * 8192 + 1000                     # two wavefronts, the second nearly empty, last packet short
+    data = synth.text(12, n)
+    npk = H.packet_count(n)
+    slots = H.encode(torch.from_numpy(data).cuda())
+    last_clen = int(slots[(npk - 1) * 8704].item()) | (int(slots[(npk - 1) * 8704 + 1].item()) << 8)
+    size = (npk - 1) * 8704 + last_clen      # the caller's buffer ends with the last packet
+    d_out = torch.full((npk * 8192,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    lib.garDecompressExecutor(slots.data_ptr(), size, d_out.data_ptr(), (npk + 31) // 32)
+    torch.cuda.synchronize()
+    assert lib.gpuar_hip_last_error() == 0 and H.status() == 0
+    assert np.array_equal(d_out[:n].cpu().numpy(), data)
+    assert bool((d_out[n:] == 0x5A).all())
+    # one byte less and the last slot no longer starts inside: floor -> it is left alone
+    d_out.fill_(0x5A)
+    lib.garDecompressExecutor(slots.data_ptr(), (npk - 1) * 8704, d_out.data_ptr(), (npk + 31) // 32)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out[:(npk - 1) * 8192].cpu().numpy(), data[:(npk - 1) * 8192])
+    assert bool((d_out[(npk - 1) * 8192:] == 0x5A).all())
+
+
+@pytest.mark.parametrize("shift", [0, 4, 8, 12])
+def test_decode_stream_at_every_allowed_alignment(H, oracle, shift):
+    """gpuar_hip_decode_stream documents a 4-byte aligned stream pointer: the same stream at base + 0/4/8/12
+    (the wavefront's 16-byte piece grid is then skewed against the packets), with short packets in the MIDDLE of
+    the stream (lanes of different lengths inside one wavefront: the PLAIN variant of the symbol step and the
+    partial-block tail, away from the end of the file), a 1-byte packet among them."""
+    rng = np.random.default_rng(77 + shift)
+    lens = [8192] * 130
+    for at, ln in ((3, 100), (40, 8191), (64, 1), (65, 4097), (100, 63), (101, 64), (102, 65), (129, 5000)):
+        lens[at] = ln
+    packets = [synth.zipf(100 + i, ln) if i % 3 else rng.integers(0, 256, ln, dtype=np.uint8) for i, ln in enumerate(lens)]
+    stream = np.concatenate([oracle.encode_stream(p) for p in packets])
+    offs = np.zeros(len(lens) + 1, dtype=np.int64)
+    at = 0
+    for i, p in enumerate(packets):
+        offs[i] = at
+        at += int(stream[at]) | (int(stream[at + 1]) << 8)
+    offs[len(lens)] = at
+    assert at == stream.size
+    raw = torch.zeros(stream.size + 64, dtype=torch.uint8, device="cuda")
+    base = (-raw.data_ptr()) % 16 + shift                    # 16-byte aligned + shift
+    raw[base:base + stream.size] = torch.from_numpy(stream).cuda()
+    d_stream = raw[base:base + stream.size]
+    assert d_stream.data_ptr() % 16 == shift
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_out = torch.full((len(lens) * 8192,), 0xC3, dtype=torch.uint8, device="cuda")
+    H.decode_stream(d_stream, torch.from_numpy(offs).cuda(), len(lens), d_out, d_status=word)
+    torch.cuda.synchronize()
+    assert int(word.item()) == 0
+    got = d_out.cpu().numpy().reshape(len(lens), 8192)
+    for i, p in enumerate(packets):
+        assert np.array_equal(got[i, :p.size], p), (shift, i, p.size)
+        assert bool((got[i, p.size:] == 0xC3).all()), (shift, i)      # a short packet writes only its ulen bytes
 
 
 def test_round_trip_properties_at_scale(H):
@@ -284,7 +385,7 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config"]
+           "--gib-per-gpu", "0.25", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -312,16 +413,29 @@ def _self_launched_bench(extra, tmp_path):
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
-    d = _self_launched_bench(["--gib-per-gpu", "0.25"], tmp_path)
+    d = _self_launched_bench(["--gib-per-gpu", "0.25", "--total-gib", "0.5"], tmp_path)
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak"
     assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True and d["device_status"] == 0
     assert abs(d["compression_ratio"] - 1.00804) < 1e-3
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 0.25 * 1.073741824) < 1e-6    # both ranks' bytes over the time
+    # what an 8-GPU run must carry in the same line: per-rank kernel times, the other scaling mode,
+    # and the staged-copy vs gather measurement
+    pr = d["per_rank"]
+    assert 0 < pr["encode_ms_min"] <= pr["encode_ms_max"] and 0 < pr["decode_ms_min"] <= pr["decode_ms_max"]
+    assert len(pr["compressed_bytes"]) == 2
+    o = d["other_scaling"]
+    assert o["scaling"] == "strong" and o["roundtrip_equal"] is True and o["value"] > 0 and o["total_bytes"] == 1 << 29
+    g = d["gather_probe"]
+    assert g["ranks"] == 2 and g["bytes_per_rank"] > 0 and g["staged_d2h_ms"] > 0 and g["gather_then_d2h_ms"] > 0
+    assert g["cheaper"] in ("staged hipMemcpyAsync", "RCCL gather")
+    for k in ("compact_ms", "encode_plus_compact_ms", "decode_stream_ms", "roofline_compact", "roofline_decode_stream"):
+        assert k in d, k
+    assert d["decode_stream_roundtrip_equal"] is True
 
 
 def test_bench_strong_scaling_splits_one_stream(tmp_path):
     """configs[3] in miniature: a fixed total split into contiguous packet ranges, one per rank."""
-    d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5"], tmp_path)
+    d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5", "--gib-per-gpu", "0.25"], tmp_path)
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong"
     assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 0.5 * 1.073741824) < 1e-6           # the total, not per rank

@@ -1,3 +1,6 @@
+#!/usr/bin/env bash
+# Wall time of `gpuar c` / `gpuar d` on an 8 GiB page-cached file for several chunk sizes (--batch, packets per chunk).
+# Usage (GPU box, repository root):  bash tools/cli_sweep.sh
 set -u
 B=gpuar_amd/bin/gpuar; D=/tmp; G=8
 python3 - <<PY

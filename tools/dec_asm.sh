@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
-# extracts decode_slots_kernel from build/gpuar_kernels.s into /tmp/dec.s
-cd /root/repo/build || exit 1
-s=$(grep -n "^_ZN5gpuar19decode_slots_kernelEPKhjPh:" gpuar_kernels.s | cut -d: -f1)
-e=$(grep -n "\.Lfunc_end1:" gpuar_kernels.s | cut -d: -f1)
-awk -v s=$s -v e=$e 'NR>=s && NR<=e' gpuar_kernels.s > /tmp/dec.s
-wc -l /tmp/dec.s
+# Cuts decode_slots_kernel out of build/gpuar_kernels.s (after `make -C gpuar_amd/csrc asm`) into build/dec.s.
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+src="$root/build/gpuar_kernels.s"
+[ -f "$src" ] || { echo "run: make -C gpuar_amd/csrc asm" >&2; exit 2; }
+awk '/^_ZN5gpuar19decode_slots_kernel.*:$/,/s_endpgm/' "$src" > "$root/build/dec.s"
+wc -l "$root/build/dec.s"

@@ -1,7 +1,22 @@
 #!/usr/bin/env bash
 # tools/exp_build.sh NAME "-DEXP_A=1 -DEXP_B=2"  -> gpuar_amd/lib/exp/NAME.so   (experiment builds for tools/ab_timing.sh)
-mkdir -p /root/repo/gpuar_amd/lib/exp
-cd /root/repo/gpuar_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/root/repo/include -Wno-unused-function \
-  -mllvm -phi-node-folding-threshold=64 -mllvm -two-entry-phi-node-folding-threshold=64 $2 -shared \
-  -o /root/repo/gpuar_amd/lib/exp/$1.so /root/repo/build/host_codec.o gpuar_kernels.hip 2>&1 | grep -E "error|warning: v" 
-exit 0
+# Builds from the working tree with extra flags.  A failed build removes the stale library and exits non-zero,
+# so ab_timing.sh can never time yesterday's binary under today's name.
+set -u
+if [ $# -lt 1 ]; then echo "usage: $0 NAME [\"extra hipcc flags\"]" >&2; exit 2; fi
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+arch="${GPUAR_ARCH:-gfx950}"
+hipcc="${HIPCC:-/opt/rocm/bin/hipcc}"
+out="$root/gpuar_amd/lib/exp/$1.so"
+mkdir -p "$root/gpuar_amd/lib/exp" "$root/build"
+rm -f "$out"
+[ -f "$root/build/host_codec.o" ] || make -C "$root/gpuar_amd/csrc" "$root/build/host_codec.o" > /dev/null || exit 1
+log="$(mktemp)"
+( cd "$root/gpuar_amd/csrc" && "$hipcc" --offload-arch="$arch" -O3 -std=c++17 -fPIC -I"$root/include" -Wno-unused-function \
+    -mllvm -phi-node-folding-threshold=64 -mllvm -two-entry-phi-node-folding-threshold=64 ${2:-} -shared \
+    -o "$out" "$root/build/host_codec.o" gpuar_kernels.hip ) > "$log" 2>&1
+rc=$?
+grep -E "error|warning: v" "$log"
+rm -f "$log"
+if [ $rc -ne 0 ]; then rm -f "$out"; echo "exp_build: $1 FAILED (rc $rc)" >&2; exit $rc; fi
+echo "built $out"

@@ -80,6 +80,15 @@ __global__ void __launch_bounds__(64) probe(unsigned long long *out, int iters) 
         if (K == 66) asm volatile(REP16(R_ROUND(ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
         if (K == 67) asm volatile(REP16(R_ROUND(ADD8 ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
         if (K == 68) asm volatile(REP16(R_ROUND(ADD8 ADD8 ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+#define RW2(WR, N_ADDS) "ds_read2_b64 v[100:103], %9 offset1:64\n " WR " %9, v[104:105] offset:8192\n" N_ADDS "s_waitcnt lgkmcnt(1)\n v_and_b32 %9, 0x1f8, v100\n"
+        if (K == 70) asm volatile(REP16(RW2("ds_write_b64", ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 71) asm volatile(REP16(RW2("ds_add_u64", ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 72) asm volatile(REP16(RW2("ds_write_b64", ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 73) asm volatile(REP16(RW2("ds_add_u64", ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 74) asm volatile(REP16(RW2("ds_write_b64", ADD8 ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 75) asm volatile(REP16(RW2("ds_add_u64", ADD8 ADD8 ADD8)) : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 76) asm volatile(REP16("ds_read2_b64 v[100:103], %9 offset1:64\n" ADD8 ADD8 ADD8 "s_waitcnt lgkmcnt(0)\n v_and_b32 %9, 0x1f8, v100\n") : OPS : CLOBBER, "v100", "v101", "v102", "v103");
+        if (K == 77) asm volatile(REP16("ds_read2_b64 v[100:103], %9 offset1:64\n ds_write_b64 %9, v[104:105] offset:8192\n ds_read_b32 v106, %9 offset:16384\n" ADD8 ADD8 ADD8 "s_waitcnt lgkmcnt(1)\n v_and_b32 %9, 0x1f8, v100\n") : OPS : CLOBBER, "v100", "v101", "v102", "v103", "v106");
         if (K == 55) asm volatile(REP16("ds_read_b32 v100, %9\n s_waitcnt lgkmcnt(0)\n v_and_b32 %9, 0x3f0, v100\n") : OPS : CLOBBER, "v100", "v101", "v102", "v103");
         if (K == 56) asm volatile(REP16("ds_read_b64 v[100:101], %9\n s_waitcnt lgkmcnt(0)\n v_and_b32 %9, 0x3f0, v100\n") : OPS : CLOBBER, "v100", "v101", "v102", "v103");
     }
@@ -154,6 +163,16 @@ int main() {
     run<54>(d, "ds_read_b128, 32 adds in its shadow, wait (per round trip)", 16);
     run<55>(d, "ds_read_b32 -> wait -> address from data (per round trip)", 16);
     run<56>(d, "ds_read_b64 -> wait -> address from data (per round trip)", 16);
+    run<70>(d, "ds_read2_b64 + ds_write_b64 behind it,  8 adds, wait(1)", 16);
+    run<71>(d, "ds_read2_b64 + ds_add_u64   behind it,  8 adds, wait(1)", 16);
+    run<72>(d, "ds_read2_b64 + ds_write_b64 behind it, 16 adds, wait(1)", 16);
+    run<73>(d, "ds_read2_b64 + ds_add_u64   behind it, 16 adds, wait(1)", 16);
+    run<74>(d, "ds_read2_b64 + ds_write_b64 behind it, 24 adds, wait(1)", 16);
+    run<75>(d, "ds_read2_b64 + ds_add_u64   behind it, 24 adds, wait(1)", 16);
+    run<76>(d, "ds_read2_b64 alone, 24 adds, wait(0)", 16);
+    run<77>(d, "ds_read2_b64 + ds_write_b64 + ds_read_b32 behind it, 24 adds, wait(1)", 16);
+    run_full<72>(d, "ds_read2_b64 + ds_write_b64 behind it, 16 adds, wait(1)", 16);
+    run_full<73>(d, "ds_read2_b64 + ds_add_u64   behind it, 16 adds, wait(1)", 16);
     run_full<0>(d, "v_add_u32 chain, distance 1 (per instruction)", 64);
     run_full<2>(d, "v_add_u32 four chains (per instruction)", 256);
     run_full<4>(d, "v_mul_u32_u24 four chains (per instruction)", 256);

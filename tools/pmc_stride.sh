@@ -1,3 +1,10 @@
+#!/usr/bin/env bash
+# FETCH_SIZE / WRITE_SIZE of the codec kernels for two builds that differ in the slot stride (8704 vs 8832 bytes):
+# is the encoder's write amplification an L2 set-aliasing effect of the 8704-byte stride?  (It is not: DESIGN.md 4.2.)
+# Usage (GPU box, repository root):  bash tools/pmc_stride.sh
+#   expects gpuar_amd/lib/exp/base.so and gpuar_amd/lib/exp/slot8832.so
+#   (tools/exp_build.sh base "" ; tools/exp_build.sh slot8832 "-DGPUAR_SLOT_BYTES=8832u")
+for lib in base slot8832; do [ -f "gpuar_amd/lib/exp/$lib.so" ] || { echo "missing gpuar_amd/lib/exp/$lib.so (see the usage note in this script)" >&2; exit 2; }; done
 repo=$(pwd); out=$repo/gpurun_out/pmc_stride; rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 for v in base:8704 slot8832:8832; do lib=${v%%:*}; sl=${v##*:};
  for c in FETCH_SIZE WRITE_SIZE; do

@@ -28,7 +28,7 @@ def main(out):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("== PMC counters: per-dispatch average")
     for k in sorted(pmc):
-        if k.startswith("generate") or k.startswith("scan") or k.startswith("gather"):
+        if k.startswith("generate") or k.startswith("scan"):
             continue
         print(f"-- {k}")
         for c, v in sorted(pmc[k].items()):

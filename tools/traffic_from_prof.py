@@ -31,7 +31,8 @@ def main(out_dir, tag, gib, kind="uniform"):
     for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            key = "encode" if "encode_kernel" in name else "decode" if "decode_slots_kernel" in name else None
+            key = ("encode" if "encode_kernel" in name else "decode" if "decode_slots_kernel" in name else
+                   "decode_stream" if "decode_stream_kernel" in name else "gather" if "gather_kernel" in name else None)
             if key:
                 vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/prof_run.py --gib {gib} --kind {kind}",
@@ -53,7 +54,7 @@ def main(out_dir, tag, gib, kind="uniform"):
             res[k]["valu_busy_per_simd"] = avg("SQ_ACTIVE_INST_VALU") * 4.0 / (avg("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
         if d.get("SQ_INSTS_VALU"):
             res[k]["valu_insts_per_symbol_step"] = avg("SQ_INSTS_VALU") / symbol_steps
-    path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+    path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json" if kind == "uniform" and gib == 8 else f"{tag}_traffic_{kind}_{gib:g}gib.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res))
 

@@ -35,6 +35,30 @@ __global__ void __launch_bounds__(64) probe(uint32_t *out, int iters, int dyn_un
         if (KIND == 20) asm volatile(REP64("v_sub_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n v_sub_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
         if (KIND == 21) asm volatile(REP64("v_bfm_b32 %0, %0, %2\n v_bfm_b32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
         if (KIND == 22) asm volatile(REP64("v_subb_co_u32 %0, vcc, %0, %2, vcc\n v_subb_co_u32 %1, vcc, %1, %2, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 23) asm volatile(REP64("v_and_b32 %0, 0x407f, %0\n v_and_b32 %1, 0x607f, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 24) asm volatile(REP64("v_and_b32 %0, s20, %0\n v_and_b32 %1, s21, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 25) asm volatile(REP64("v_bitop3_b32 %0, %0, s20, %2 bitop3:0xc8\n v_bitop3_b32 %1, %1, s20, %2 bitop3:0xc8\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 26) asm volatile(REP64("v_or_b32 %0, %0, %2\n v_or_b32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 27) asm volatile(REP64("v_xor_b32 %0, %0, %2\n v_xor_b32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 28) asm volatile(REP64("v_sub_u32 %0, %0, %2\n v_sub_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 29) asm volatile(REP64("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 30) asm volatile(REP64("v_min_u32 %0, %0, %2\n v_min_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 31) asm volatile(REP64("v_max_u32 %0, %0, %2\n v_max_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 32) asm volatile(REP64("v_mov_b32 %0, %2\n v_mov_b32 %1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 33) asm volatile(REP64("v_lshl_add_u32 %0, %0, 1, %2\n v_lshl_add_u32 %1, %1, 1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 34) asm volatile(REP64("v_sub_co_u32 %0, vcc, %0, %2\n v_sub_co_u32 %1, vcc, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 35) asm volatile(REP64("v_sub_co_u32 %0, s[22:23], %0, %2\n v_sub_co_u32 %1, s[22:23], %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 36) asm volatile(REP64("v_addc_co_u32 %0, vcc, %0, %2, vcc\n v_addc_co_u32 %1, vcc, %1, %2, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 37) asm volatile(REP64("v_mul_u32_u24_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n v_mul_u32_u24_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 38) asm volatile(REP64("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 39) asm volatile(REP64("v_mul_f32 %0, %0, %2\n v_mul_f32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 40) asm volatile(REP64("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 41) asm volatile(REP64("v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 42) asm volatile(REP64("v_pk_mul_lo_u16 %0, %0, %2\n v_pk_mul_lo_u16 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 43) asm volatile(REP64("v_mul_lo_u32 %0, %0, %2\n v_mul_lo_u32 %1, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 44) asm volatile(REP64("v_mad_u64_u32 %4, vcc, %0, %2, %4\n v_mad_u64_u32 %4, vcc, %1, %2, %4\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 45) asm volatile(REP64("v_add_u32_dpp %0, %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
+        if (KIND == 46) asm volatile(REP64("v_and_or_b32 %0, %0, %2, %3\n v_and_or_b32 %1, %1, %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(w) : : "vcc", "s20", "s21", "s22", "s23");
     }
     if (a + b + (uint32_t)w == 0x12345) out[blockIdx.x] = a + pad[0];
 }
@@ -86,5 +110,29 @@ int main() {
     run<20>("v_sub_u32_sdwa");
     run<21>("v_bfm_b32 (VOP3)");
     run<22>("v_subb_co_u32 (VOP2)");
+    run<23>("v_and_b32 literal (VOP2 + 32-bit literal)");
+    run<24>("v_and_b32 sgpr (VOP2)");
+    run<25>("v_bitop3_b32 (VOP3)");
+    run<26>("v_or_b32 (VOP2)");
+    run<27>("v_xor_b32 (VOP2)");
+    run<28>("v_sub_u32 (VOP2)");
+    run<29>("v_lshlrev_b32 (VOP2)");
+    run<30>("v_min_u32 (VOP2)");
+    run<31>("v_max_u32 (VOP2)");
+    run<32>("v_mov_b32 (VOP1)");
+    run<33>("v_lshl_add_u32 (VOP3)");
+    run<34>("v_sub_co_u32 -> vcc (VOP2)");
+    run<35>("v_sub_co_u32 -> sgpr (VOP3)");
+    run<36>("v_addc_co_u32 vcc (VOP2)");
+    run<37>("v_mul_u32_u24_sdwa");
+    run<38>("v_fma_f32 (VOP3)");
+    run<39>("v_mul_f32 (VOP2)");
+    run<40>("v_cvt_f32_u32 (VOP1)");
+    run<41>("v_pk_add_u16 (VOP3P)");
+    run<42>("v_pk_mul_lo_u16 (VOP3P)");
+    run<43>("v_mul_lo_u32 (VOP3)");
+    run<44>("v_mad_u64_u32 (VOP3)");
+    run<45>("v_add_u32 DPP row_shr:1");
+    run<46>("v_and_or_b32 literal (VOP3 + literal)");
     return 0;
 }
