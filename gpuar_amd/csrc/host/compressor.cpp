@@ -1,5 +1,8 @@
 #include "compressor.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cstdlib>
 
 #include "gpuar_hip.h"
@@ -15,10 +18,16 @@ Compressor::Compressor() {}
 
 Compressor::~Compressor() { closeFiles(); }
 
-void Compressor::openFiles() {
+void Compressor::openFiles(bool truncate_output) {
     openFile = std::fopen(openFileName.c_str(), "rb");
     if (!openFile) throw std::runtime_error("Can not open input file: " + openFileName);
-    saveFile = std::fopen(saveFileName.c_str(), "wb");
+    if (truncate_output) {
+        saveFile = std::fopen(saveFileName.c_str(), "wb");
+    } else {
+        const int fd = ::open(saveFileName.c_str(), O_CREAT | O_WRONLY, 0666);
+        saveFile = fd < 0 ? nullptr : ::fdopen(fd, "wb");
+        if (fd >= 0 && !saveFile) ::close(fd);
+    }
     if (!saveFile) {
         closeFiles();
         throw std::runtime_error("Can not open output file: " + saveFileName);

@@ -45,7 +45,9 @@ class Compressor {
         return claimed >= 20 && claimed <= fileSize ? claimed : fileSize;
     }
 
-    void openFiles();                 // throws std::runtime_error naming the file
+    // throws std::runtime_error naming the file.  truncate_output = false: an existing output file keeps its pages
+    // (dropping 8 GiB of page cache costs most of a second); the caller sets the final length itself
+    void openFiles(bool truncate_output = true);
 
   public:
     Compressor();

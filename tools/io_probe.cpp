@@ -2,6 +2,7 @@
 // of page-cached files by thread count, PCIe copies, and whether a mapped file can be registered for DMA.
 // Build: g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o tools/io_probe.bin tools/io_probe.cpp -L/opt/rocm/lib -lamdhip64 -lpthread
 // Run (GPU box): ./tools/io_probe.bin [dir, default /tmp] [GiB, default 2]
+#include <errno.h>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <sys/mman.h>
@@ -229,6 +230,17 @@ int main(int argc, char **argv) {
         for (auto &t : ts) t.join();
         const double t = now() - t0;
         printf("D2H 1 GiB into registered 64 MiB windows of the output mapping, %d threads %7.3f s (%6.2f GB/s)\n", threads, t, chunk / t / 1e9);
+        close(fd);
+    }
+    for (int threads : {1, 4, 8}) {   // O_DIRECT: past the page cache, to whatever device backs the directory
+        unlink(out.c_str());
+        const int fd = open(out.c_str(), O_CREAT | O_WRONLY | O_TRUNC | O_DIRECT, 0644);
+        if (fd < 0) { printf("O_DIRECT open failed: %s\n", strerror(errno)); break; }
+        if (posix_fallocate(fd, 0, chunk) != 0) perror("fallocate");
+        bool bad = false;
+        const double t = parallel(threads, chunk, [&](size_t b, size_t e) {
+            while (b < e) { const size_t io = std::min<size_t>(16u << 20, e - b); ssize_t g = pwrite(fd, pin + b, io, b); if (g <= 0) { bad = true; break; } b += g; } });
+        printf("pwrite 1 GiB pinned -> O_DIRECT file, %2d threads %7.3f s (%6.2f GB/s)%s\n", threads, t, chunk / t / 1e9, bad ? "  FAILED" : "");
         close(fd);
     }
     {   // is the data really in the file?
