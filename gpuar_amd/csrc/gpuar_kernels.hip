@@ -446,7 +446,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
             "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
-#ifdef GPUAR_EXP_DSADD
 #define GPUAR_A_SHADOW_CARRIED \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
             64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left, set by that symbol's step; v205: lx if lmc, \
@@ -456,25 +455,12 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 
 #define GPUAR_A_SHADOW_PLAIN \
             "ds_add_u64 %[oaddr], v[204:205]\n\t" /* the increments of the previous symbol's low half, formed by its own step */
-#else
-#define GPUAR_A_SHADOW_CARRIED \
-         /* in its shadow: the half of the PREVIOUS symbol's low record its path went through (lbw, lcc as read) gets its \
-            increments (lincb: +1 on the count, +0x10000 on the child if left; lx if lmc: the grandchild) and goes back */ \
-            "v_add_u32 v204, %[lbw], %[lincb]\n\t" \
-            "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t" \
-            "v_add_u32 v205, %[lcc], %[lx]\n\t" \
-            "ds_write_b64 %[oaddr], v[204:205]\n\t" \
-
-#define GPUAR_A_SHADOW_PLAIN \
-            "ds_write_b64 %[oaddr], v[204:205]\n\t" /* the previous symbol's low half, rebuilt by its own step */
-#endif
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
             "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
             "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
 
-#ifdef GPUAR_EXP_DSADD
 #define GPUAR_MID_WRITEBACK \
             "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
@@ -484,19 +470,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 v209, 0, %[t2], %[mc]\n\t" \
             "ds_add_u64 %[am], v[208:209]\n\t"
-#else
-#define GPUAR_MID_WRITEBACK \
-            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
-            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
-         /* ---- the mid half updated and written back in the shadow of read #2 */ \
-            "v_add_u32 v208, %[bw], %[t3]\n\t" \
-            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
-            "v_cndmask_b32 %[t2], 0, %[t2], %[mc]\n\t" \
-            "v_add_u32 v209, %[cc], %[t2]\n\t" \
-            "ds_write_b64 %[am], v[208:209]\n\t"
-#endif
 #define GPUAR_BC_MID \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: v200 = aR | bR << 16, v201 = cRR | cRL << 16 (right half), v202 = a | bL << 16, v203 = cLR | cLL << 16 (left half) */ \
@@ -568,7 +541,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
 
-#ifdef GPUAR_EXP_DSADD
 #define GPUAR_BC_TAIL_CARRIED \
          /* ---- what the next step adds to this low half (in the shadow of its first read) */ \
             "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
@@ -579,20 +551,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 v205, 0, %[t2], %[lmc]\n\t"
-#else
-#define GPUAR_BC_TAIL_CARRIED \
-         /* ---- what the next step needs to update this low half (it does so in the shadow of its first read) */ \
-            "v_cndmask_b32 %[lincb], 1, %[k64k1], vcc\n\t" \
-            "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
-
-#define GPUAR_BC_TAIL_PLAIN \
-         /* ---- the low half updated -> v204:v205 (written back by the next step) */ \
-            "v_cndmask_b32 %[t3], 1, %[k64k1], vcc\n\t" \
-            "v_add_u32 v204, %[lbw], %[t3]\n\t" \
-            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
-            "v_cndmask_b32 %[t2], 0, %[t2], %[lmc]\n\t" \
-            "v_add_u32 v205, %[lcc], %[t2]\n\t"
-#endif
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
@@ -632,7 +590,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, a, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx;
 
-#ifdef GPUAR_EXP_DSADD
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
         GPUAR_STEP_LOCALS \
@@ -646,20 +603,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
-#else
-#define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
-    { \
-        GPUAR_STEP_LOCALS \
-        unsigned long long lma_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
-            : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "+v"(lbw), [lcc] "+v"(lcc), [lx] "+v"(lx), [lincb] "+v"(lincb), [lma] "=&s"(lma_), [lmc] "+s"(lmc) \
-            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
-        NP_OUT = np; \
-    }
-#endif
 
 #define GPUAR_DECODE_SYMBOL_PLAIN(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
     { \
@@ -838,7 +781,6 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 
     // ---- blocks that every lane of the wavefront owns: uniform control flow, CARRIED variant ----
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
-#ifdef GPUAR_EXP_DSADD
     {
         // v204:v205 = the 64-bit increment the previous symbol's low half still has to take (added in the shadow of the
         // next step's first read); nothing is owed yet: an add of zero to the half reset() named.
@@ -853,28 +795,6 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         // the increment still owed, completed the way the step does: v204:v205 then hold what is to be added
         asm volatile("v_cndmask_b32 v205, 0, %[lx], %[lmc]" : "+v"(o0), "+v"(o1) : [lx] "v"(lx), [lmc] "s"(lmc));
     }
-#else
-    {
-        uint32_t lbw, lcc, lincb, lx;
-        unsigned long long lmc;
-        // The write-back the plain step still owes, in carried form: with no increments and an empty lane mask the
-        // update yields (lbw, lcc) as they are.  (Initial values go through asm: a known constant would be
-        // spliced into the statements as an immediate.)
-        asm volatile("s_mov_b64 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0" : "=s"(lmc), "=v"(lincb), "=v"(lx));
-        lbw = dec.model.owed.w0, lcc = dec.model.owed.w1;
-        for (; i + 64u <= len_min; i += 64u) {
-            GPUAR_ROTATE_RECIPS
-            GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
-        }
-        // update the low half still owed the way the step does: v204:v205 then hold what is to be written
-        asm volatile(
-            "v_add_u32 v204, %[lbw], %[lincb]\n\t"
-            "v_cndmask_b32 %[lx], 0, %[lx], %[lmc]\n\t"
-            "v_add_u32 v205, %[lcc], %[lx]\n\t"
-            : "=&v"(o0), "=&v"(o1), [lx] "+v"(lx)
-            : [lbw] "v"(lbw), [lcc] "v"(lcc), [lincb] "v"(lincb), [lmc] "s"(lmc));
-    }
-#endif
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
     //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
     for (; i + 64u <= len_max; i += 64u) {
@@ -892,7 +812,6 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     dec.next = (next64 >> 6) - skew16;
     dec.off = offr;
     dec.owed_bits = nbits;
-#ifdef GPUAR_EXP_DSADD
     // the increment still owed goes in now; what the plain step is then handed as "owed" is a rewrite of that half with
     // the values it holds (its write_back stores, it does not add)
     asm volatile("ds_add_u64 %[oaddr], v[204:205]\n\ts_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1) : [oaddr] "v"(oaddr) : "memory");
@@ -901,10 +820,6 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         const Pair now = load64(col + dec.model.owed.at);
         dec.model.owed.w0 = now.w[0], dec.model.owed.w1 = now.w[1];
     }
-#else
-    dec.model.owed.at = oaddr - col_lds;
-    dec.model.owed.w0 = o0, dec.model.owed.w1 = o1;
-#endif
     dec.bad = dec.bad || bad_min < 0x80000000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block

@@ -40,8 +40,6 @@
 #define GPUAR_ALIGNBIT(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
 // x as a value the compiler cannot see through (keeps it from re-associating the expression x feeds)
 #define GPUAR_OPAQUE_V(x) ([](uint32_t x_) { asm("" : "+v"(x_)); return x_; }((x)))
-// a constant held in a scalar register instead of being spliced into every instruction as a 32-bit literal
-#define GPUAR_CONST_S(c) ([]() { uint32_t r_; asm("s_mov_b32 %0, %1" : "=s"(r_) : "i"(c)); return r_; }())
 // the load that produces q is issued here, before any later store (no wait is implied)
 #define GPUAR_PIN_LOAD(q) asm volatile("" : : : "memory")
 // materialise x here and keep memory operations on their side of this point
@@ -61,7 +59,6 @@
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #define GPUAR_OPAQUE_V(x) (x)
-#define GPUAR_CONST_S(c) (c)
 #endif
 
 namespace gpuar {
@@ -215,12 +212,11 @@ struct InorderModel {
 
     // x_tag = (x << kRowShift) | lane_bits, formed once per symbol; the node
     // address is then ONE two-operand AND (a full-rate instruction) plus a
-    // compile-time offset the LDS instruction carries as an immediate.
-#ifdef GPUAR_EXP_TAG_AND
+    // compile-time offset the LDS instruction carries as an immediate.  The tag
+    // is made opaque: hipcc otherwise folds the OR into every level's AND as a
+    // three-operand v_bitop3_b32, which costs twice the issue time of v_and_b32
+    // (tools/valu_probe.hip: 4.6 against 2.3-2.7 cycles per SIMD slot).
     GPUAR_LANE uint32_t tag(uint32_t x) const { return GPUAR_OPAQUE_V((x << kRowShift) | lane_bits); }
-#else
-    GPUAR_LANE uint32_t tag(uint32_t x) const { return (x << kRowShift) | lane_bits; }
-#endif
     GPUAR_LANE uint16_t *node(uint32_t x_tag, int k) const {
         const uint32_t keep = (((0xFF00u >> k) & 0xFFu) << kRowShift) | ((1u << kRowShift) - 1u);
         const uint32_t fixed = ((1u << (7 - k)) - 1u) << kRowShift;
@@ -244,20 +240,11 @@ struct PartialModeler {
     uint32_t root, half0, half1;            // kHead >= 1: depth 0; kHead == 2: depth 1 as well
     uint32_t left[kDepths];                 // this part's nodes of the NEXT symbol to account
     uint16_t *where[kDepths];
-#ifdef GPUAR_EXP_PICK_SGPR
-    uint32_t kpick;
-#define GPUAR_KPICK kpick
-#else
-#define GPUAR_KPICK 0x10001u
-#endif
 
     // table: first byte of the shared node table; lane_bits: this lane's byte offset inside a row
     GPUAR_LANE void open(uint8_t *table, uint32_t lane_bits, uint32_t first_symbol) {
         tree.table = table;
         tree.lane_bits = lane_bits;
-#ifdef GPUAR_EXP_PICK_SGPR
-        kpick = GPUAR_CONST_S(0x10001);
-#endif
         // initial counts, own rows only (the other part initialises its own)
 #pragma unroll 1
         for (uint32_t row = 0; row < 255u; ++row) {
@@ -285,16 +272,16 @@ struct PartialModeler {
     GPUAR_LANE uint32_t step_last(uint32_t x, uint32_t total, uint32_t onto = 0) {
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24((z >> 8) & GPUAR_KPICK, total, onto);
+        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);
         if (kHead >= 1) {
-            const uint32_t pick0 = (z >> 7) & GPUAR_KPICK;
+            const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
         }
         static_assert(kHead < 2, "step_last: depth 1 in registers is not carried here");
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
-            const uint32_t pick = (z >> (7 - (kFirst + k))) & GPUAR_KPICK;
+            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
             acc = GPUAR_MAD24(l, pick, acc);
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));
@@ -307,15 +294,15 @@ struct PartialModeler {
         const uint32_t xn = tree.tag(x_next);
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24((z >> 8) & GPUAR_KPICK, total, onto);  // x == 255: cumHi is the whole total
+        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);  // x == 255: cumHi is the whole total
         if (kHead >= 1) {
-            const uint32_t pick0 = (z >> 7) & GPUAR_KPICK;
+            const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
         }
         if (kHead >= 2) {
             const bool upper_half = x >= 128u;
-            const uint32_t pick1 = (z >> 6) & GPUAR_KPICK;
+            const uint32_t pick1 = (z >> 6) & 0x10001u;
             acc = GPUAR_MAD24(upper_half ? half1 : half0, pick1, acc);
             const uint32_t quarter = x >> 6;
             half0 += quarter == 0u ? 1u : 0u;
@@ -323,7 +310,7 @@ struct PartialModeler {
         }
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
-            const uint32_t pick = (z >> (7 - (kFirst + k))) & GPUAR_KPICK;
+            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
             acc = GPUAR_MAD24(l, pick, acc);
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left

@@ -25,6 +25,9 @@ t $B d --in=$D/u.gip --out=$D/u.back
 t $B d --in=$D/u_idx.gip --out=$D/u.back2
 t $B d --in=$D/u_idx.gip --out=$D/u.back2
 GPUAR_NO_MMAP=1 t $B c --in=$D/u.dat --out=$D/u_nommap.gip
+echo "-- the pipeline's own timeline (GPUAR_TRACE=1): where the wall time goes"
+GPUAR_TRACE=1 $B c --in=$D/u.dat --out=$D/u.gip 2>&1 | tr -d '\r' | grep -E "^\[gpuar|\[gpuar" | sed -e 's/^.*\[gpuar/[gpuar/' | sed -e 's/^/   c: /'
+GPUAR_TRACE=1 $B d --in=$D/u.gip --out=$D/u.back 2>&1 | tr -d '\r' | grep -E "\[gpuar" | sed -e 's/^.*\[gpuar/[gpuar/' | sed -e 's/^/   d: /'
 cmp $D/u.gip $D/u_nommap.gip && echo "unmapped-input file identical"
 cmp $D/u.dat $D/u.back && cmp $D/u.dat $D/u.back2 && echo roundtrip-ok
 rm -f $D/u.dat $D/u.gip $D/u_idx.gip $D/u.back $D/u.back2 $D/u_nommap.gip
