@@ -514,6 +514,8 @@ struct SubtreeModel {
     // decision chose, with +1 on its count (a or aR: every symbol that lands in the record lands in one of
     // the two halves), on the child if the second decision went left and on the grandchild if the third
     // did -- ONE 8-byte store at an address that is one shift-add of the path, no select.
+    // (The GPU's hand-scheduled step, gpuar_kernels.hip, applies the same three increments to the half in place with
+    // one 64-bit LDS add instead of rebuilding and storing it: no field can carry into its neighbour.)
     struct Path {
         uint32_t at;                    // byte offset of the half from `col`
         uint32_t w0, w1;
