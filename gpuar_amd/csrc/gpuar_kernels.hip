@@ -16,8 +16,8 @@
 //    wavefront makes the workgroup cover all four SIMDs so that roles can be
 //    dealt out per SIMD;
 //  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
-//    two 16-byte subtree records per symbol instead of walking eight levels, writes
-//    back the 8-byte half of each that the path went through, and
+//    two 16-byte subtree records per symbol instead of walking eight levels, applies
+//    the increments of the 8-byte half of each that the path went through by one 64-bit LDS add, and
 //    works on a scaled remainder (no division, borrow = path bit); the symbol step
 //    is a hand-scheduled instruction stream; the packet stream reaches it through a
 //    per-lane ring in LDS, the per-symbol constants through v_readlane;
@@ -399,13 +399,14 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 // vector load the whole wavefront waits for (~720 cycles under load, longer than the step) -- the
 // loop below contains neither.  The compiler's own schedule of lane_codec.h's
 // step_symbol spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane
-// mask it writes); the statement below spends ~98 vector + 5 LDS.
+// mask it writes); the statement below spends ~94 vector + 5 LDS.
 //
 //   R0 = off*total + total - 1; depths 0 and 1 (registers); READ #1 (mid record) issued
-//       in its shadow: the half of the previous symbol's low record that its path took, updated and written
-//       back; register nodes bumped
+//       in its shadow: the half of the previous symbol's low record that its path took takes its increments
+//       (one ds_add_u64: count +1, child +1 if left, grandchild +1 if left -- fields stay below 2^14, nothing
+//       carries into a neighbour); register nodes bumped
 //   wait; mid record: 3 decisions; READ #2 (low record) issued
-//       in its shadow: the mid record's half updated and written back; the stream window steps over the
+//       in its shadow: the mid record's half takes its increments the same way; the stream window steps over the
 //       previous symbol's bits (refill from the LDS ring), peek
 //   wait; low record: 3 decisions, Z for the upper bound; interval narrowed and renormalised;
 //       off = ((off - dn) : window) << n
@@ -424,12 +425,16 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
 
 // One symbol of the hand-scheduled decoder (see above), in text pieces.  Two variants are assembled from them:
-//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the low half of a
-//            symbol is updated by the NEXT symbol's step, in the shadow of its first LDS read, from the two dwords
-//            as read (lbw, lcc) and the path (lincb, lx and the lane mask lmc) -- lane masks can only be carried
-//            from one statement to the next in scalar registers where the compiler sees uniform control flow;
+//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the increments of a symbol's
+//            low half are completed by the NEXT symbol's step, in the shadow of its first LDS read, from what this
+//            step leaves behind (v204: the count/child increment, lx and the lane mask lmc: the grandchild's) --
+//            lane masks can only be carried from one statement to the next in scalar registers where the compiler
+//            sees uniform control flow;
 //   PLAIN    for the one wavefront of a file that holds its short last packet (lanes drop out under `if`):
-//            the step updates the half itself into v204:v205.
+//            the step forms the whole 64-bit increment itself, in v204:v205.
+// Either way the next step applies it with one ds_add_u64 (profiles/r03_decode_cost_attribution.txt: an LDS add costs
+// this wavefront ~20 cycles to issue, a ds_write_b64 ~28, and the four vector instructions that used to rebuild the
+// half's two dwords are gone; WAITED for, an LDS atomic is 60-440 cycles dearer than a write, tools/lat_probe.hip).
 // They use decode_wave's locals by name.
 #define GPUAR_A_HEAD \
             "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
@@ -491,7 +496,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             GPUAR_MID_WRITEBACK
 
 #define GPUAR_BC_LOW \
-            "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid record's write-back, perhaps the stream reader's dword) */ \
+            "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
          /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
                  Z = R - V with V = scaled distance from the walk's origin to the upper end of the subtree it is in: \
                  S * range on entry (S = a + aR, all eight symbols under the record); going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
@@ -650,7 +655,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         atomicOr(status, GPUAR_STATUS_BAD_PACKET);
         return;
     }
-    register uint32_t o0 asm("v204");          // PLAIN: the low half of the previous symbol, updated, not yet written back
+    register uint32_t o0 asm("v204");          // the increments the previous symbol's low half still has to take (v204:v205)
     register uint32_t o1 asm("v205");
     register uint32_t offr asm("v217");        // code - lo; v216:v217 is the pair the 64-bit shift of the window works on
     offr = dec.off;
