@@ -543,6 +543,9 @@ def main(argv=None):
         result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes, c_total,
                                  all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic)
         result.update(side)
+        for key, rec in (("roofline_compact", "gather"), ("roofline_decode_stream", "decode_stream")):
+            if rec in traffic:                      # the PMC passes cover these kernels too (tools/prof_run.py --only all)
+                result[key]["traffic"] = traffic[rec].get("hbm_bytes_per_launch")
         result["per_rank"] = {
             "encode_ms_min": min(r[4] for r in rows) / 1e3, "encode_ms_max": max(r[4] for r in rows) / 1e3,
             "decode_ms_min": min(r[5] for r in rows) / 1e3, "decode_ms_max": max(r[5] for r in rows) / 1e3,

@@ -79,6 +79,30 @@ def test_traffic_is_quoted_only_for_the_kernels_it_was_measured_on(tmp_path):
     assert stub_line([], traffic=t)["roofline"]["traffic"] is None
 
 
+def test_traffic_record_is_picked_by_workload(tmp_path):
+    """profiles/ may hold one record per stream kind and size: the one taken on THIS workload is quoted."""
+    os.makedirs(tmp_path / "profiles")
+    for rel in bench.KERNEL_SOURCES:
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        (tmp_path / rel).write_text("kernel v1")
+    stamp = bench.kernel_source_stamp(str(tmp_path))
+    for name, kind, gib, hbm in (("r09_traffic.json", "uniform", 8.0, 1.9e10), ("r09_traffic_text_8gib.json", "text", 8.0, 1.4e10),
+                                 ("r09_traffic_uniform_0.0625gib.json", "uniform", 0.0625, 1.5e8)):
+        rec = {"source": "pmc", "input_gib": gib, "kind": kind, "kernel_source_sha256_16": stamp,
+               "encode": {"hbm_bytes_per_launch": hbm}, "decode": {"hbm_bytes_per_launch": hbm}, "gather": {"hbm_bytes_per_launch": hbm}}
+        (tmp_path / "profiles" / name).write_text(json.dumps(rec))
+    assert bench.load_profiled_traffic("text", 8 * GIB, root=str(tmp_path))["decode"]["hbm_bytes_per_launch"] == 1.4e10
+    assert bench.load_profiled_traffic("uniform", 8 * GIB, root=str(tmp_path))["gather"]["hbm_bytes_per_launch"] == 1.9e10
+    assert bench.load_profiled_traffic("uniform", GIB // 16, root=str(tmp_path))["encode"]["hbm_bytes_per_launch"] == 1.5e8
+    assert "decode" not in bench.load_profiled_traffic("zipf", 8 * GIB, root=str(tmp_path))
+
+
+def test_usable_cpus_is_the_affinity_cut_by_the_cgroup_quota():
+    n, how = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and how in ("sched_getaffinity", "cgroup cpu.max", "cgroup cfs_quota")
+    assert n <= len(os.sched_getaffinity(0))
+
+
 def test_committed_traffic_record_matches_the_committed_kernels_or_is_declared_stale():
     t = bench.load_profiled_traffic("uniform", 8 * GIB)
     assert ("decode" in t) or ("STALE" in t["source"]) or ("no profiles" in t["source"])

@@ -226,3 +226,29 @@ def test_gpu_cli_names_the_chunk_of_a_corrupted_packet(tmp_path):
     open(gip, "wb").write(blob)
     assert run("d", f"--in={gip}", f"--out={back}", "--batch=64").returncode == 0
     assert open(back, "rb").read() == data.tobytes()
+
+
+def test_gpu_cli_overwrites_a_longer_file_and_leaves_nothing_behind_on_failure(tmp_path):
+    """The GPU path opens its output WITHOUT truncating it (dropping the page cache of a large old file costs most of
+    a second) and sets the length itself at the end: over an older, longer file the result must still be exactly the
+    fresh one -- in both directions -- and a job that fails must not leave a half-written file that looks like a result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, fresh, reused, back = tmp_path / "in.dat", tmp_path / "fresh.gip", tmp_path / "reused.gip", tmp_path / "back.dat"
+    data = synth.text(33, 200 * 8192 + 17)
+    data.tofile(src)
+    junk = np.random.default_rng(1).integers(0, 256, 5 << 20, dtype=np.uint8).tobytes()     # longer than any output here
+    assert run("c", f"--in={src}", f"--out={fresh}").returncode == 0
+    reused.write_bytes(junk)
+    assert run("c", f"--in={src}", f"--out={reused}").returncode == 0
+    assert reused.read_bytes() == fresh.read_bytes()
+    back.write_bytes(junk)
+    assert run("d", f"--in={reused}", f"--out={back}").returncode == 0
+    assert back.read_bytes() == data.tobytes()
+    # failure: a stream cut in the middle of a packet
+    cut = tmp_path / "cut.gip"
+    cut.write_bytes(fresh.read_bytes()[:-100])
+    back.write_bytes(junk)
+    r = run("d", f"--in={cut}", f"--out={back}")
+    assert r.returncode == 1
+    assert back.stat().st_size == 0
