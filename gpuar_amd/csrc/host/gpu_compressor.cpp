@@ -622,7 +622,8 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         trace(mapped.data() ? "compress: input mapped" : "compress: input NOT mapped (pread path)");
         // room for the worst case up front: writing into allocated blocks is faster than growing the file, and the real
         // length is set at the end (best effort: a file system without fallocate just grows the file as it goes)
-        (void)::posix_fallocate(out_fd, 0, static_cast<off_t>(FileHeader::HEADER_LENGTH + total_packets * kSlot));
+        // (the fallocate system call, not posix_fallocate: where the file system cannot do it, glibc's stand-in would write zeros)
+        (void)::fallocate(out_fd, 0, 0, static_cast<off_t>(FileHeader::HEADER_LENGTH + total_packets * kSlot));
         std::vector<std::vector<uint16_t>> chunk_clens(writeIndex ? n_chunks : 0);     // for the optional index trailer
         std::vector<std::atomic<size_t>> next_of_device(G);
         for (auto &n : next_of_device) n = 0;
@@ -918,7 +919,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         }
 
         // what the packet count promises, allocated up front (best effort); the real length is set at the end
-        (void)::posix_fallocate(out_fd, 0, static_cast<off_t>(static_cast<uint64_t>(expect_packets) * kPacket));
+        (void)::fallocate(out_fd, 0, 0, static_cast<off_t>(static_cast<uint64_t>(expect_packets) * kPacket));
         OrderedOffsets place;
         std::vector<std::atomic<size_t>> next_of_device(G);
         for (auto &n : next_of_device) n = 0;
