@@ -252,3 +252,30 @@ def test_gpu_cli_overwrites_a_longer_file_and_leaves_nothing_behind_on_failure(t
     r = run("d", f"--in={cut}", f"--out={back}")
     assert r.returncode == 1
     assert back.stat().st_size == 0
+
+
+def test_gpu_cli_empty_input_and_input_without_a_mapping(tmp_path):
+    """Edge cases of the pipeline: an empty file (no chunk, no packet: header only, and it decodes to an empty file),
+    and the pread path of an input that cannot be mapped (GPUAR_NO_MMAP=1) -- same bytes as the mapped path, both ways."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    empty, gip, back = tmp_path / "empty.dat", tmp_path / "empty.gip", tmp_path / "empty.back"
+    empty.write_bytes(b"")
+    r = run("c", f"--in={empty}", f"--out={gip}")
+    assert r.returncode == 0, r.stderr
+    blob = gip.read_bytes()
+    assert len(blob) == 20 and int.from_bytes(blob[4:12], "little") == 0 and int.from_bytes(blob[12:20], "little") == 20
+    r = run("d", f"--in={gip}", f"--out={back}")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == b""
+    src, a, b, back2 = tmp_path / "in.dat", tmp_path / "mapped.gip", tmp_path / "pread.gip", tmp_path / "back2.dat"
+    data = synth.zipf(44, 300 * 8192 + 5)
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={a}", "--batch=128").returncode == 0
+    env = dict(os.environ, GPUAR_NO_MMAP="1")
+    r = subprocess.run([CLI, "c", f"--in={src}", f"--out={b}", "--batch=128"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert a.read_bytes() == b.read_bytes()
+    r = subprocess.run([CLI, "d", f"--in={b}", f"--out={back2}", "--batch=64"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert back2.read_bytes() == data.tobytes()
