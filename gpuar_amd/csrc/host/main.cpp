@@ -163,10 +163,13 @@ int main(int argc, char **argv) {
                   << std::endl;
         // The files are closed and the statistics printed: leave without tearing the GPU context down buffer by buffer
         // (unpinning and freeing a few GiB takes a tenth of a second the user would wait for; the process is ending anyway).
-        std::cout.flush();
-        std::cerr.flush();
-        (void)compressor.release();
-        std::_Exit(0);
+        // (GPUAR_NO_FAST_EXIT=1 keeps the ordinary exit path: a profiler writes its files from an exit handler)
+        if (!std::getenv("GPUAR_NO_FAST_EXIT")) {
+            std::cout.flush();
+            std::cerr.flush();
+            (void)compressor.release();
+            std::_Exit(0);
+        }
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return 1;
