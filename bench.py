@@ -148,6 +148,8 @@ def load_profiled_traffic(kind, n_bytes, root=ROOT, stamp=None):
             if k in t:
                 out[k] = t[k]
         return out
+    # the reason that concerns THIS workload first (a stale record of it), then the others
+    why.sort(key=lambda w: 0 if "STALE" in w else 1)
     return {"source": "; ".join(why[:3])}
 
 

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gpuar_hip.h"
@@ -377,6 +378,210 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         if (live) {
             bool overflowed;
             coder.finish(len, overflowed);
+            if (overflowed) atomicOr(status, GPUAR_STATUS_SLOT_OVERFLOW);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Encode, LATENCY mode: inputs too small to fill the chip (at most kSmallGroups groups of 64 packets).
+//
+// Such a launch takes as long as ONE packet: 8192 serial symbol steps of the slowest role, whatever the chip could do
+// next to it -- the three-role kernel above needs ~355 cycles per step there (its coder's own chain), the same for 64
+// packets as for 65536.  With the chip mostly idle and LDS plentiful, the step is cut finer instead: SIX wavefronts
+// per 64 packets, each one phase (8 symbols) behind the one before it.  A wavefront with few neighbours pays ~4.5
+// cycles per vector instruction AND 12-20 per LDS operation, so the tree -- two LDS operations per
+// level -- is what has to be spread thinnest:
+//     UPPER    depths 1-2 of the tree; reads the input, hands the bytes on            13 vector + 5.5 LDS per symbol
+//     MID1     depths 3-4, added onto the sums in place                               13 + 6
+//     MID2     depths 5-6, added in place                                             13 + 6
+//     LOW      depth 0 (register), depth 7, the x == 255 term, added in place         15 + 4
+//     INTERVAL interval narrowing + renormalisation counts -> one word per symbol     ~24 + 2   (lane_codec.h IntervalLane)
+//     SINK     pending bits, accumulator, stores                                      ~31 + 1   (SinkLane)
+// Same integers as the throughput kernel (lane_codec.h is shared; tests/test_lane_emulation.py pins the cut coder
+// and a three-way tree against the oracle on the CPU), a different cut.  Rings: five slots of sums, four of input
+// bytes, two of interval words: 48 KiB of LDS per workgroup.  Every role meets n_phases + 5 barriers.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSmallGroups = 512;       // up to 32768 packets = 256 MiB of input: at most two workgroups per CU
+constexpr uint32_t kSmallLag = 5;            // the last role works five phases behind the first
+constexpr uint32_t kSumSlots = kSmallLag;    // a slot of sums is alive from UPPER's phase to INTERVAL's, four phases later
+constexpr uint32_t kByteBufs = 4;            // the bytes of a phase are read by MID1, MID2 and LOW, up to three phases later
+#ifndef GPUAR_SMALL_PHASE
+#define GPUAR_SMALL_PHASE 8
+#endif
+constexpr uint32_t kSmallPhase = GPUAR_SMALL_PHASE;   // symbols per phase: the roles meet at a barrier once per phase (must be 8 or 16)
+struct EncodeSmallLds {
+    uint8_t tree[kTreeRows * kLanes * 2];     // 32 KiB
+    uint32_t sums[kSumSlots][kSmallPhase][kLanes];    // [slot][symbol][lane], cumLo | cumHi << 16 in the making
+    uint32_t bytes[kByteBufs][kSmallPhase / 4][kLanes];    // the input bytes of a phase
+    uint32_t words[2][kSmallPhase][kLanes];   // IntervalLane -> SinkLane
+};
+
+// the input bytes of one phase at in + at (a multiple of the phase length), zero beyond `len`
+struct PhaseBytes {
+    uint32_t w[kSmallPhase / 4];
+};
+__device__ __forceinline__ PhaseBytes load_phase(const uint8_t *in, uint32_t at, uint32_t len) {
+    PhaseBytes r;
+    if (at + kSmallPhase <= len) {
+#pragma unroll
+        for (uint32_t q = 0; q < kSmallPhase / 8; ++q) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(in + at + 8u * q);
+            r.w[2 * q] = v.x, r.w[2 * q + 1] = v.y;
+        }
+        return r;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kSmallPhase / 4; ++q) {            // (static positions: the words stay in registers)
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b)
+            if (at + 4u * q + b < len) v |= static_cast<uint32_t>(in[at + 4u * q + b]) << (8u * b);
+        r.w[q] = v;
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t byte_of(const PhaseBytes &p, uint32_t j) {      // j static
+    return (p.w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+}
+
+__device__ __forceinline__ void small_upper(EncodeSmallLds &lds, const uint8_t *in, uint32_t lane, uint32_t len, uint32_t len_min,
+                                            uint32_t n_phases) {
+    PartialModeler<7, 1, 2, 0, false> model;
+    PhaseBytes cur, nxt = load_phase(in, 0, len);
+    model.open(lds.tree, 2u * lane_column(lane), nxt.w[0] & 0xFFu);
+    for (uint32_t k = 0; k < n_phases + kSmallLag; ++k) {
+        if (k < n_phases) {
+            const uint32_t base = k * kSmallPhase;
+            cur = nxt;
+            nxt = load_phase(in, base + kSmallPhase, len);
+#pragma unroll
+            for (uint32_t q = 0; q < kSmallPhase / 4; ++q) lds.bytes[k % kByteBufs][q][lane] = cur.w[q];
+            uint32_t *out = &lds.sums[k % kSumSlots][0][lane];
+            if (base + kSmallPhase <= len_min) {
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j)
+                    out[j * kLanes] = model.step(byte_of(cur, j), 256u + base + j, j + 1u < kSmallPhase ? byte_of(cur, j + 1u) : nxt.w[0] & 0xFFu);
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j)
+                    if (base + j < len)
+                        out[j * kLanes] = model.step(byte_of(cur, j), 256u + base + j, j + 1u < kSmallPhase ? byte_of(cur, j + 1u) : nxt.w[0] & 0xFFu);
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// MIDDLE and LOW: `lag` phases behind UPPER; bytes and the sums so far come through LDS, the sums go back in place
+template <typename Model>
+__device__ __forceinline__ void small_follow(EncodeSmallLds &lds, uint32_t lane, uint32_t len, uint32_t len_min, uint32_t n_phases, uint32_t lag) {
+    Model model;
+    model.open(lds.tree, 2u * lane_column(lane), 0u);
+    for (uint32_t b = 0; b < lag; ++b) lds_barrier();
+    for (uint32_t k = 0; k < n_phases; ++k) {
+        const uint32_t base = k * kSmallPhase;
+        uint32_t *io = &lds.sums[k % kSumSlots][0][lane];
+        PhaseBytes w;
+#pragma unroll
+        for (uint32_t q = 0; q < kSmallPhase / 4; ++q) w.w[q] = lds.bytes[k % kByteBufs][q][lane];
+        if (base + kSmallPhase <= len_min) {
+            uint32_t part[kSmallPhase];
+#pragma unroll
+            for (uint32_t j = 0; j < kSmallPhase; ++j) part[j] = io[j * kLanes];
+            model.prime(w.w[0] & 0xFFu);
+#pragma unroll
+            for (uint32_t j = 0; j < kSmallPhase; ++j)
+                io[j * kLanes] = j + 1u < kSmallPhase ? model.step(byte_of(w, j), 256u + base + j, byte_of(w, j + 1u), part[j])
+                                                      : model.step_last(byte_of(w, j), 256u + base + j, part[j]);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kSmallPhase; ++j) {          // (unrolled: the byte's position must be static)
+                const uint32_t x = byte_of(w, j);
+                if (base + j < len) {
+                    model.prime(x);
+                    io[j * kLanes] = model.step_last(x, 256u + base + j, io[j * kLanes]);
+                }
+            }
+        }
+        lds_barrier();
+    }
+    for (uint32_t b = lag; b < kSmallLag; ++b) lds_barrier();
+}
+
+__global__ void __launch_bounds__(6 * kLanes)
+encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets, uint32_t *__restrict__ status) {
+    __shared__ EncodeSmallLds lds;
+    const size_t group = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t packet = group * kLanes + lane;
+    const bool live = packet < n_packets;
+    const size_t start = packet * kPacket;
+    const uint32_t len = live ? static_cast<uint32_t>(size - start < kPacket ? size - start : kPacket) : 0u;
+    const uint32_t len_max = wave_max(len);
+    const uint32_t len_min = wave_max(~len) ^ 0xFFFFFFFFu;
+    const uint32_t n_phases = (len_max + kSmallPhase - 1) / kSmallPhase;
+    const uint8_t *in = src + (live ? start : 0);
+    // The dispatcher deals a workgroup's wavefronts round the four SIMDs: wavefronts 0 and 4 share one, 1 and 5 another;
+    // the four tree roles pair up there (one's LDS operations issue under the other's vector instructions), the two
+    // coder roles have a SIMD each.
+    if (wave == 1u) {
+        small_upper(lds, in, lane, len, len_min, n_phases);
+    } else if (wave == 4u) {
+        small_follow<PartialModeler<7, 3, 2, 0, false>>(lds, lane, len, len_min, n_phases, 1u);
+    } else if (wave == 5u) {
+        small_follow<PartialModeler<7, 5, 2, 0, false>>(lds, lane, len, len_min, n_phases, 2u);
+    } else if (wave == 0u) {
+        small_follow<LowModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
+    } else if (wave == 2u) {
+        IntervalLane interval;
+        interval.open();
+        for (uint32_t b = 0; b < kSmallLag - 1u; ++b) lds_barrier();
+        for (uint32_t k = 0; k < n_phases; ++k) {
+            const uint32_t base = k * kSmallPhase;
+            const uint32_t *sums = &lds.sums[k % kSumSlots][0][lane];
+            uint32_t *out = &lds.words[k & 1u][0][lane];
+            if (base + kSmallPhase <= len_min) {
+                uint32_t cums[kSmallPhase];
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j) cums[j] = sums[j * kLanes];
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j) out[j * kLanes] = interval.step(cums[j], g_recip.r[base + j]);
+            } else {
+#pragma unroll 1
+                for (uint32_t j = 0; j < kSmallPhase; ++j) {
+                    if (base + j >= len_max) break;
+                    const Recip r = g_recip.r[base + j];
+                    if (base + j < len) out[j * kLanes] = interval.step(sums[j * kLanes], r);
+                }
+            }
+            lds_barrier();
+        }
+        lds_barrier();
+    } else {
+        SinkLane sink;
+        sink.open(dst + group * (kLanes * kSlot), lane * kSlot);
+        for (uint32_t b = 0; b < kSmallLag; ++b) lds_barrier();
+        for (uint32_t k = 0; k < n_phases; ++k) {
+            const uint32_t base = k * kSmallPhase;
+            const uint32_t *in_words = &lds.words[k & 1u][0][lane];
+            if (base + kSmallPhase <= len_min) {
+                uint32_t w[kSmallPhase];
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j) w[j] = in_words[j * kLanes];
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j) sink.take(w[j]);
+            } else {
+#pragma unroll 1
+                for (uint32_t j = 0; j < kSmallPhase; ++j)
+                    if (base + j < len) sink.take(in_words[j * kLanes]);
+            }
+            lds_barrier();
+        }
+        if (live) {
+            bool overflowed;
+            sink.finish(len, overflowed);
             if (overflowed) atomicOr(status, GPUAR_STATUS_SLOT_OVERFLOW);
         }
     }
@@ -1097,6 +1302,19 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t groups = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
+    // Small inputs cannot fill the chip and take as long as one packet: they go to the latency-mode kernel (five
+    // roles, a shorter step).  GPUAR_ENCODE_MODE=throughput|latency pins the choice (tests run both on the same
+    // inputs; the slots are the same bytes either way).
+    bool latency = groups <= gpuar::kSmallGroups;
+    if (const char *mode = getenv("GPUAR_ENCODE_MODE")) {
+        if (!strcmp(mode, "throughput")) latency = false;
+        if (!strcmp(mode, "latency")) latency = true;
+    }
+    if (latency) {
+        gpuar::encode_small_kernel<<<groups, 6 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+            d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
+        return check_launch();
+    }
     const uint32_t blocks = (groups + 7u) & ~7u;              // see xcd_contiguous_group
     gpuar::encode_kernel<<<blocks, 4 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);

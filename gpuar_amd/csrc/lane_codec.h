@@ -473,6 +473,59 @@ struct CoderLane {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The coder cut in two, for the LATENCY-mode encoder (encode_small_kernel: inputs too small to fill the chip, where
+// the time of a launch is 8192 serial symbol steps of its slowest role and LDS is plentiful).  IntervalLane owns the
+// interval (applySymbolRange :256-299 and the closed-form renormalisation counts), SinkLane owns everything about
+// bits (pending underflow bits, accumulator, stores: writeEncodedBits' output side :321-367, writeRemaining :379-388,
+// writeClose :430-439).  They are joined by ONE word per symbol: the e agreed bits, e, u and bit 14 of the new lower
+// bound (what flush needs).  Same integers as CoderLane::step, cut at the line where `agreed` is formed.
+// ---------------------------------------------------------------------------
+struct IntervalLane {
+    uint32_t lo, range, kff;
+    GPUAR_LANE void open() {
+        lo = 0;
+        range = 0x10000u;
+        kff = 0xFFFFu;
+    }
+    // agreed bits [15:0] | e [20:16] | u [29:24] | bit 14 of the new lo [31]
+    GPUAR_LANE uint32_t step(uint32_t cums, Recip rc) {
+        const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
+        const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
+        const uint32_t a = lo + dn;
+        const uint32_t wd = up - dn;
+        const uint32_t h = a + wd - 1u;
+        const uint32_t e = GPUAR_CLZ32_NZ(GPUAR_XOR_HI(kff, a, h));
+        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        const uint32_t shift = e + u;
+        const uint32_t moved = a << shift;
+        lo = moved & 0x7FFFu;
+        range = wd << shift;
+        const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
+        return agreed | (e << 16) | (u << 24) | ((moved << 17) & 0x80000000u);
+    }
+};
+
+struct SinkLane : CoderLane {
+    GPUAR_LANE void take(uint32_t packed) {
+        const uint32_t agreed = packed & 0xFFFFu, e = (packed >> 16) & 0x1Fu, u = (packed >> 24) & 0x3Fu;
+        lo = (packed >> 17) & 0x4000u;                         // all finish() looks at
+        const uint32_t em1 = e - 1u;
+        const bool shift_out = e != 0u;
+        uint32_t bits = agreed + GPUAR_BFM(pending, em1);
+        uint32_t count = e + pending;
+        const bool long_run = shift_out & (pending > 16u);    // rare: more than 16 underflow bits owed
+        if (long_run) {
+            const uint32_t top = (agreed >> (em1 & 31u)) & 1u;
+            put_bit_then_run(top, pending);
+            bits = agreed & GPUAR_BFM(em1, 0u);
+            count = em1;
+        }
+        put(shift_out ? bits : 0u, shift_out ? count : 0u);
+        pending = (shift_out ? 0u : pending) + u;
+    }
+};
+
 // ===========================================================================
 // DECODER (arDecompress :848-892).  The symbol search
 // (getSymbolFromProbability :727-763) touches LDS in two round trips of one

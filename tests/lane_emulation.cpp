@@ -84,6 +84,59 @@ int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     return any_overflow;
 }
 
+// The latency-mode encoder's five roles (encode_small_kernel): the tree dealt 3 + 3 + (0, 7, tail) to three modelers
+// that add their parts onto each other in phases of 8 symbols, the coder cut into IntervalLane and SinkLane joined
+// by one word per symbol.
+int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+{
+    int any_overflow = 0;
+    const size_t np = (n_bytes + kPacket - 1) / kPacket;
+    std::vector<uint16_t> table(kTreeRows);
+    constexpr uint32_t kPhase = 8;
+    for (size_t p = 0; p < np; ++p) {
+        const size_t off = p * kPacket;
+        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
+        PartialModeler<1, 1, 3, 0, false> upper;
+        PartialModeler<1, 4, 3, 0, false> middle;
+        LowModeler<1> low;
+        uint8_t *t = reinterpret_cast<uint8_t *>(table.data());
+        upper.open(t, 0, in[off]);
+        middle.open(t, 0, 0);
+        low.open(t, 0, 0);
+        IntervalLane interval;
+        interval.open();
+        SinkLane sink;
+        sink.open(slots, static_cast<uint32_t>(p * kSlot));
+        for (uint32_t base = 0; base < len; base += kPhase) {
+            const uint32_t count = len - base < kPhase ? len - base : kPhase;
+            uint32_t sums[kPhase];
+            for (uint32_t j = 0; j < count; ++j) {
+                const uint32_t i = base + j;
+                sums[j] = upper.step(in[off + i], 256u + i, i + 1 < len ? in[off + i + 1] : 0u);
+            }
+            middle.prime(in[off + base]);
+            for (uint32_t j = 0; j < count; ++j) {
+                const uint32_t i = base + j;
+                sums[j] = j + 1 < count ? middle.step(in[off + i], 256u + i, in[off + i + 1], sums[j])
+                                        : middle.step_last(in[off + i], 256u + i, sums[j]);
+            }
+            low.prime(in[off + base]);
+            for (uint32_t j = 0; j < count; ++j) {
+                const uint32_t i = base + j;
+                sums[j] = j + 1 < count ? low.step(in[off + i], 256u + i, in[off + i + 1], sums[j])
+                                        : low.step_last(in[off + i], 256u + i, sums[j]);
+            }
+            uint32_t words[kPhase];
+            for (uint32_t j = 0; j < count; ++j) words[j] = interval.step(sums[j], kRecip.r[base + j]);
+            for (uint32_t j = 0; j < count; ++j) sink.take(words[j]);
+        }
+        bool ov;
+        sink.finish(len, ov);
+        any_overflow |= ov ? 1 : 0;
+    }
+    return any_overflow;
+}
+
 // What a decoder wavefront's lane does (SubtreeModel + DecoderLane).
 // pkt_offsets: np+1 byte offsets into `stream`; out: np * 8192 bytes.
 // Returns the number of packets flagged bad.

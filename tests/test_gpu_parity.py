@@ -35,6 +35,19 @@ def oracle():
     return O.best()
 
 
+@pytest.fixture(params=["latency", "throughput"])
+def encode_mode(request):
+    """gpuar_hip_encode sends small inputs to the five-role latency-mode kernel and large ones to the three-role
+    throughput kernel (GPUAR_ENCODE_MODE pins the choice): the small parity cases run through BOTH kernels."""
+    old = os.environ.get("GPUAR_ENCODE_MODE")
+    os.environ["GPUAR_ENCODE_MODE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GPUAR_ENCODE_MODE"]
+    else:
+        os.environ["GPUAR_ENCODE_MODE"] = old
+
+
 def oracle_slots(codec, data: np.ndarray):
     """The packet slots the oracle says `data` codes to: (slots[npk, 8704] zero-padded, clen[npk], total bytes).
     Built from the best oracle on the box (the reference's own codec when oracle/_ref is there)."""
@@ -66,7 +79,7 @@ def gpu_stream(H, data: np.ndarray):
 
 
 @pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
-def test_encode_matches_reference_fixture(H, c):
+def test_encode_matches_reference_fixture(H, c, encode_mode):
     data = case_input(c)
     stream, offs, d_slots, npk = gpu_stream(H, data)
     assert H.status() == 0
@@ -82,7 +95,7 @@ def test_encode_matches_reference_fixture(H, c):
 
 
 @pytest.mark.parametrize("s", SURVEY["streams"], ids=lambda s: f"{s['kind']}-{s['seed']}-{s['n']}")
-def test_encode_matches_reference_cli_streams(H, s):
+def test_encode_matches_reference_cli_streams(H, s, encode_mode):
     """BASELINE.json configs[1]: 64 MiB stand-in for data/random_64m.dat on one GPU,
     packet stream byte-equal (md5) to the reference's --host output; plus the small cases."""
     n = s["n"]
@@ -109,7 +122,7 @@ def test_device_generators_match_numpy(H):
 
 @pytest.mark.parametrize("kind", ["uniform", "zipf", "text", "zeros"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 8191, 8192, 8193, 64 * 8192, 64 * 8192 + 1, 200 * 8192 + 4097])
-def test_slots_equal_oracle(H, oracle, kind, n):
+def test_slots_equal_oracle(H, oracle, kind, n, encode_mode):
     data = synth.generate(kind, 21, n)
     want_slots, lens, total = oracle_slots(oracle, data)
     d_slots = H.encode(torch.from_numpy(data).cuda())
@@ -331,7 +344,7 @@ def test_compaction_offsets_beyond_4gib(H):
     assert H.status() == 0
 
 
-def test_many_mixed_packets_against_oracle(H, oracle):
+def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
     """2048 packets, every one from a different source model (uniform, k-symbol, geometric, long
     runs, ramps, near-midpoint pairs, constant): slot-for-slot equality with the oracle, then decode."""
     rng = np.random.default_rng(20261003)

@@ -37,6 +37,8 @@ def emu():
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_encode_slots_phased.restype = C.c_int
     lib.emu_encode_slots_phased.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_split.restype = C.c_int
+    lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
@@ -94,6 +96,18 @@ def test_phased_modelers_give_the_same_slots(emu, c):
     want, npk, ov = emu_encode(emu, data)
     got = np.zeros_like(want)
     assert emu.emu_encode_slots_phased(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_latency_mode_roles_give_the_same_slots(emu, c):
+    """encode_small_kernel's five roles: the tree dealt 3 + 3 + (0, 7, tail) to three modelers that add onto each
+    other, the coder cut into IntervalLane | SinkLane joined by one word per symbol (agreed bits, e, u, bit 14 of lo).
+    Same slots as the straight emulation -- the adversarial packet that owes 2396 underflow bits included."""
+    data = np.ascontiguousarray(case_input(c))
+    want, npk, ov = emu_encode(emu, data)
+    got = np.zeros_like(want)
+    assert emu.emu_encode_slots_split(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov
     assert np.array_equal(got, want)
 
 

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("encode_kernel", "decode_slots_kernel", "decode_stream_kernel", "gather_kernel", "scan_", "generate_"):
+    for k in ("encode_small_kernel", "encode_kernel", "decode_slots_kernel", "decode_stream_kernel", "gather_kernel", "scan_", "generate_"):
         if k in name:
             return k.rstrip("_")
     return name[:40]

@@ -31,7 +31,7 @@ def main(out_dir, tag, gib, kind="uniform"):
     for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            key = ("encode" if "encode_kernel" in name else "decode" if "decode_slots_kernel" in name else
+            key = ("encode" if "encode_kernel" in name or "encode_small_kernel" in name else "decode" if "decode_slots_kernel" in name else
                    "decode_stream" if "decode_stream_kernel" in name else "gather" if "gather_kernel" in name else None)
             if key:
                 vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
