@@ -594,6 +594,7 @@ def main(argv=None):
         s_total = int(s_off[-1].item())
         result["small_config"] = {
             "workload": "uniform(42) 64 MiB (stand-in for data/random_64m.dat), 1 GPU, 8192 packets = 128 groups of 64",
+            "encode_kernel": "encode_small_kernel (latency mode: six roles per 64 packets; gpuar_hip_encode's choice up to 256 MiB)",
             "encode_GBps": m / (min(e) * 1e-3) / 1e9, "decode_GBps": m / (min(d) * 1e-3) / 1e9,
             "gip_bytes": s_total + 20,
             "stream_md5": hashlib.md5(s_stream[:s_total].cpu().numpy().tobytes()).hexdigest(),
