@@ -729,7 +729,6 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
-            "v_min_u32 %[bad], %[bad], %[t3]\n\t" /* Z >= 0 at the leaf: no symbol owns this code value */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_sub_u32 %[t1], %[R0], %[t3]\n\t" /* cumHi * range */ \
@@ -791,7 +790,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
               [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), \
               [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
-              [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [bad] "+v"(bad_min), [oaddr] "+v"(oaddr), \
+              [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [oaddr] "+v"(oaddr), \
               [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), [n] "+v"(nbits), \
               [dn] "=&v"(dn), [bw] "=&v"(bw), [cc] "=&v"(cc), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), \
               [a] "=&v"(a), [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
@@ -867,10 +866,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
     const uint32_t col_low_lds = col_lds + SubtreeModel<9>::kLowBase;               // ... and of its first low half
     uint32_t oaddr = col_lds + dec.model.owed.at;                                   // where the half owed goes
-    // min over the symbols of Z at the leaf (as u32).  A symbol owns the code value iff the remainder ends below
-    // the upper end of its leaf, Z = R - V < 0, i.e. >= 2^31 as u32 (|Z| < 2^30); a code value beyond the model's
-    // total (off >= range, where the reference stops decoding, :873-877) walks right everywhere and ends with Z >= 0
-    uint32_t bad_min = 0xFFFFFFFFu;
+    // (No check for "a code value no symbol owns" -- off >= range, where the reference stops decoding, :873-877 -- in
+    // this loop: it cannot happen, whatever the bits are.  off < range holds at the start (off < 2^16 = range); the walk
+    // finds s with cumLo*range <= R0 < cumHi*range for R0 = (off + 1)*total - 1 < range*total; then
+    // dn = floor(cumLo*range/total) <= off and (off + 1)*total <= cumHi*range gives off + 1 <= up, so
+    // 0 <= off - dn < up - dn = width, and appending n stream bits to both keeps ((off - dn) : bits) << n below
+    // width << n.  Round 2 carried a per-symbol minimum for it; 65 million symbols of garbage never raised it.)
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u, k64k1 = 0x10001u;
     uint32_t bswap_sel, ring_wrap;
@@ -1030,7 +1031,6 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         const Pair now = load64(col + dec.model.owed.at);
         dec.model.owed.w0 = now.w[0], dec.model.owed.w1 = now.w[1];
     }
-    dec.bad = dec.bad || bad_min < 0x80000000u;
     // the last, partial block of a packet whose length is not a multiple of 64 (at most one per file,
     // unless the packets are malformed): symbol by symbol, only the lanes that are inside such a block
     const uint32_t part_from = dec.ulen & ~63u;

@@ -834,9 +834,9 @@ struct DecoderLane {
     GPUAR_LANE uint32_t step_symbol(const DecodeConst &k) {
         const uint32_t R0 = GPUAR_MUL24(off, k.total) + k.total_m1;   // getUnscaledCode's numerator (:703-716)
         // No symbol owns a code value with floor(R0 / range) >= total, i.e. off >= range (:873-877,
-        // where the reference stops decoding the packet).  Such a packet is
-        // malformed: flag it and keep going -- the walk stays inside the tree and
-        // the output inside its 8192 bytes whatever the bits are.
+        // where the reference stops decoding the packet).  It cannot happen -- off < range is an invariant of
+        // the step for any bit stream (argument in gpuar_kernels.hip, decode_wave) -- so the GPU's hand-scheduled
+        // step does not look; this compiled path keeps the comparison as a guard of its own arithmetic.
         bad = bad || off >= range;
         uint32_t R, width;
         const uint32_t sym = model.decode_step(R0, range, R, width, [this]() {
