@@ -703,35 +703,34 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #define GPUAR_BC_LOW \
             "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
          /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
-                 Z = R - V with V = scaled distance from the walk's origin to the upper end of the subtree it is in: \
-                 S * range on entry (S = a + aR, all eight symbols under the record); going left V becomes the product p (>= ... <= V) and Z the difference d = R - p (negative, \
-                 and >= the old Z since p <= V); going right both R and V lose p and Z stays, while d >= 0: Z' = max_u32(Z, d). \
-                 At the leaf cumHi * range = R0 - Z: no width to carry, no select. */ \
+                 Next to the walk (three decisions on the scaled remainder) the symbol's own COUNT is picked out of the half: \
+                 under the chosen side there are `count` symbols (a or aR), `child` of them left of the child node, the \
+                 grandchild node holds the left one of the two leaves: count -> (lb ? child : count - child) -> (lc ? gc : that - gc). \
+                 Two subtractions and two selects off the chain, then cnt * range is added to cumLo * range: one instruction fewer \
+                 than carrying the scaled upper bound through the walk (round 2: Z = R - V, a sum, a product, a difference and three maxima). */ \
             "v_mul_u32_u24_sdwa %[pa], v214, %[rng]" GPUAR_SDWA_W0 \
-            "v_add_u32_sdwa %[ps], v212, v214 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t" /* S = aR + a */ \
-            "v_mul_u32_u24 %[ps], %[ps], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[lma], %[R], %[pa]\n\t" \
-            "v_sub_u32 %[t3], %[R], %[ps]\n\t" /* Z on entry */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_cndmask_b32 %[lbw], v212, v214, %[lma]\n\t" \
             "v_cndmask_b32 %[lcc], v213, v215, %[lma]\n\t" \
             "v_mul_u32_u24_sdwa %[pb], %[lbw], %[rng]" GPUAR_SDWA_W1 \
             "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
+            "v_sub_u32_sdwa %[ps], %[lbw], %[lbw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" /* count - child: right of the child node */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 9, %[collow]\n\t" /* the low half that goes back (in the next step's shadow) */ \
+            "v_lshl_add_u32 %[oaddr], %[np], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */ \
             "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
+            "v_cndmask_b32_sdwa %[ps], %[ps], %[lbw], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* symbols under the chosen grandchild node */ \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[lmc], %[R], %[pc]\n\t" \
+            "v_sub_u32 %[t3], %[ps], %[t2]\n\t" /* the right leaf */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_max_u32 %[t3], %[t3], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_cndmask_b32 %[t3], %[t3], %[t2], %[lmc]\n\t" /* cnt(symbol) */ \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
-            "v_sub_u32 %[t1], %[R0], %[t3]\n\t" /* cumHi * range */ \
+            "v_mad_u32_u24 %[t1], %[t3], %[rng], %[t0]\n\t" /* cumHi * range = cumLo * range + cnt * range */ \
             "v_mul_hi_u32 %[dn], %[t0], %[mul]\n\t" \
             "v_mul_hi_u32 %[t1], %[t1], %[mul]\n\t" \
             "v_lshrrev_b32 %[dn], %[shift], %[dn]\n\t" \
