@@ -34,6 +34,8 @@
 // a * b + c with 24-bit factors in ONE instruction (hipcc prefers separate multiplies and three-operand
 // adds to shorten the dependency chain; these kernels are bound by instruction count, not by latency)
 #define GPUAR_MAD24(a, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t r_; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "v"(b_), "v"(c_)); return r_; }((a), (b), (c)))
+// the same with the second factor uniform over the wavefront (a scalar register: no copy into a vector register)
+#define GPUAR_MAD24_VS(a, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t r_; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "s"(b_), "v"(c_)); return r_; }((a), (b), (c)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // low 32 bits of (hi:lo) >> (s & 31)
@@ -55,6 +57,7 @@
 #define GPUAR_BFM(w, off) (((1u << ((w) & 31u)) - 1u) << ((off) & 31u))
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #define GPUAR_MAD24(a, b, c) ((a) * (b) + (c))
+#define GPUAR_MAD24_VS(a, b, c) ((a) * (b) + (c))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
@@ -272,7 +275,7 @@ struct PartialModeler {
     GPUAR_LANE uint32_t step_last(uint32_t x, uint32_t total, uint32_t onto = 0) {
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);
+        if (kTail) acc = GPUAR_MAD24_VS((z >> 8) & 0x10000u, total, onto);
         if (kHead >= 1) {
             const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
@@ -294,7 +297,7 @@ struct PartialModeler {
         const uint32_t xn = tree.tag(x_next);
         const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24((z >> 8) & 0x10001u, total, onto);  // x == 255: cumHi is the whole total
+        if (kTail) acc = GPUAR_MAD24_VS((z >> 8) & 0x10000u, total, onto);  // x == 255: cumHi is the whole total
         if (kHead >= 1) {
             const uint32_t pick0 = (z >> 7) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
