@@ -868,6 +868,15 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         ChunkMap map;
         std::thread scanner;
         std::atomic<bool> stop_scan{false};
+        // whatever way this scope is left, the scanner is told to stop and joined before `map` and `mapped` go away
+        struct JoinScanner {
+            std::thread &t;
+            std::atomic<bool> &stop;
+            ~JoinScanner() {
+                stop = true;
+                if (t.joinable()) t.join();
+            }
+        } join_scanner{scanner, stop_scan};
         if (indexed) {                   // prefix sums of the stored lengths (already checked against the stream size)
             uint64_t at = FileHeader::HEADER_LENGTH;
             for (size_t p = 0; p < index.size();) {
