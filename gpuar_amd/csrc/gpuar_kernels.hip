@@ -98,14 +98,14 @@ constexpr int kPrioTop = 3, kPrioCoder = 1, kPrioLow = 0;
 // The three roles work one phase apart -- the top modeler on the symbols of phase p, the low modeler on those of
 // p - 1, the coder on those of p - 2 -- and hand a phase on IN PLACE: the top modeler writes its part of
 // cumLo | cumHi << 16 per symbol, the low modeler adds its own, the coder reads the sum.  Three phases are alive at
-// a time, so the ring has three slots.  The low modeler takes the input bytes from the top one as well (two dwords
-// per lane and phase), so only one wavefront of a group reads the input from memory.
+// a time, so the ring has three slots.  The low modeler takes the symbols from the top one as well (as the row tags
+// the top modeler forms anyway, one u16 per lane and symbol), so only one wavefront of a group reads the input from memory.
 constexpr uint32_t kRingSlots = 3;
 struct EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
     uint32_t sums[kRingSlots][kPhase][kLanes]; // 6 KiB: [slot][symbol][lane]
-    uint32_t bytes[2][2][kLanes];              // 1 KiB: [phase parity][dword][lane], the eight input bytes of a phase
-    uint32_t spare[256];                       // 1 KiB (the role hand-shake at the start uses it)
+    uint16_t tags[2][kPhase][kLanes];          // 2 KiB: [phase parity][symbol][lane], the row tags (x << 7 | lane bits) of a
+                                               // phase's symbols, from the top modeler to the low one
 };
 __device__ __forceinline__ uint32_t next_slot(uint32_t slot) { return slot == kRingSlots - 1u ? 0u : slot + 1u; }
 
@@ -186,14 +186,15 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
 #pragma unroll
             for (uint32_t ph = 0; ph < kChunkPhases; ++ph) {
                 uint32_t *out = &lds.sums[slot][0][lane];
-                lds.bytes[ph & 1u][0][lane] = w[2u * ph];                // k = kChunkPhases * q + ph, first term even
-                lds.bytes[ph & 1u][1][lane] = w[2u * ph + 1u];
+                uint16_t *tags = &lds.tags[ph & 1u][0][lane];            // k = kChunkPhases * q + ph, first term even
+                tags[0] = static_cast<uint16_t>(model.next_tag);         // the tag every step forms for its successor anyway
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {
                     const uint32_t i = ph * kPhase + j;                  // symbol index inside the chunk
                     const uint32_t x = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
                     const uint32_t x_next = (w[(i + 1) >> 2] >> (8u * ((i + 1) & 3u))) & 0xFFu;
                     out[j * kLanes] = model.step(x, 256u + q * kChunk + i, x_next);
+                    if (j + 1u < kPhase) tags[(j + 1u) * kLanes] = static_cast<uint16_t>(model.next_tag);
                 }
                 slot = next_slot(slot);
                 lds_barrier();
@@ -220,8 +221,7 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
                 else nxt = make_uint4(0, 0, 0, 0);
             }
             uint32_t *out = &lds.sums[slot][0][lane];
-            lds.bytes[k & 1u][0][lane] = words[0];
-            lds.bytes[k & 1u][1][lane] = words[1];
+            uint16_t *tags = &lds.tags[k & 1u][0][lane];
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q) {
                 uint32_t w = words[q], w_next = words[q + 1];
@@ -231,8 +231,10 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
                     const uint32_t x = w & 0xFFu;
                     w = (w >> 8) | (w_next << 24);            // next symbol now in the low byte
                     w_next >>= 8;
+                    *tags = static_cast<uint16_t>(model.next_tag);       // = tag(x) wherever i < len
                     if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
                     out += kLanes;
+                    tags += kLanes;
                 }
             }
             slot = next_slot(slot);
@@ -252,31 +254,25 @@ __device__ __forceinline__ void run_low(EncodeLds &lds, uint32_t lane, uint32_t 
     for (uint32_t k = 0; k < n_phases; ++k) {                  // the symbols of phase k, during phase k + 1
         const uint32_t base = k * kPhase;
         uint32_t *io = &lds.sums[slot][0][lane];
-        const uint32_t w0 = lds.bytes[k & 1u][0][lane], w1 = lds.bytes[k & 1u][1][lane];
+        const uint16_t *tags = &lds.tags[k & 1u][0][lane];
         if (base + kPhase <= len_min) {
-            uint32_t part[kPhase];
+            uint32_t part[kPhase], tag[kPhase];
 #pragma unroll
-            for (uint32_t j = 0; j < kPhase; ++j) part[j] = io[j * kLanes];
-            model.prime(w0 & 0xFFu);
+            for (uint32_t j = 0; j < kPhase; ++j) part[j] = io[j * kLanes], tag[j] = tags[j * kLanes];
+            model.prime_tag(tag[0]);
 #pragma unroll
             for (uint32_t j = 0; j < kPhase; ++j) {
-                const uint32_t w = j < 4u ? w0 : w1;
-                const uint32_t x = (w >> (8u * (j & 3u))) & 0xFFu;
-                if (j + 1u < kPhase) {
-                    const uint32_t wn = j + 1u < 4u ? w0 : w1;
-                    io[j * kLanes] = model.step(x, 256u + base + j, (wn >> (8u * ((j + 1u) & 3u))) & 0xFFu, part[j]);
-                } else {
-                    io[j * kLanes] = model.step_last(x, 256u + base + j, part[j]);
-                }
+                if (j + 1u < kPhase) io[j * kLanes] = model.step_tag(tag[j], 256u + base + j, tag[j + 1u], part[j]);
+                else io[j * kLanes] = model.step_last_tag(tag[j], 256u + base + j, part[j]);
             }
         } else {
 #pragma unroll 1
             for (uint32_t j = 0; j < kPhase; ++j) {
                 const uint32_t i = base + j;
-                const uint32_t x = ((j < 4u ? w0 : w1) >> (8u * (j & 3u))) & 0xFFu;
                 if (i < len) {
-                    model.prime(x);
-                    io[j * kLanes] = model.step_last(x, 256u + i, io[j * kLanes]);
+                    const uint32_t t = tags[j * kLanes];
+                    model.prime_tag(t);
+                    io[j * kLanes] = model.step_last_tag(t, 256u + i, io[j * kLanes]);
                 }
             }
         }
@@ -304,7 +300,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_ID
     const uint32_t simd = (hw >> 4) & 3u;
-    uint32_t *hello = &lds.spare[0];
+    uint32_t *hello = &lds.sums[0][0][0];                      // (the ring is not in use yet)
     if (lane == 0) hello[wave] = simd;
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID

@@ -262,48 +262,54 @@ struct PartialModeler {
     }
 
     // fetch this part's nodes of symbol x, the next one to account (what step() does for its x_next)
-    GPUAR_LANE void prime(uint32_t x) {
-        const uint32_t xs = tree.tag(x);
+    GPUAR_LANE void prime(uint32_t x) { prime_tag(tree.tag(x)); }
+    GPUAR_LANE void prime_tag(uint32_t x_tag) {
+        next_tag = x_tag;
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
-            where[k] = tree.node(xs, kFirst + k);
+            where[k] = tree.node(x_tag, kFirst + k);
             left[k] = *where[k];
         }
     }
 
+    // The path bits of x (low half) and of x + 1 (high half) side by side, kShift bits up: from the symbol itself
+    // (kShift = 0) or from its row tag (x << kRowShift) | lane_bits (kShift = kRowShift; the lane bits stay below the
+    // bits that are looked at, and adding 1 << kRowShift to the high half does not reach them).
+    GPUAR_LANE static uint32_t paths_of_symbol(uint32_t x) { return GPUAR_MUL24(x, 0x10001u) + 0x10000u; }
+    GPUAR_LANE static uint32_t paths_of_tag(uint32_t x_tag) { return GPUAR_MUL24(x_tag, 0x10001u) + (0x10000u << kRowShift); }
+
     // step() for a symbol whose successor is not known yet: nothing is fetched ahead, prime() has to follow
-    GPUAR_LANE uint32_t step_last(uint32_t x, uint32_t total, uint32_t onto = 0) {
-        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;
-        uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24_VS((z >> 8) & 0x10000u, total, onto);
-        if (kHead >= 1) {
-            const uint32_t pick0 = (z >> 7) & 0x10001u;
-            acc = GPUAR_MAD24(root, pick0, acc);
-            root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
-        }
-        static_assert(kHead < 2, "step_last: depth 1 in registers is not carried here");
-#pragma unroll
-        for (int k = 0; k < kDepths; ++k) {
-            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
-            const uint32_t l = left[k];
-            acc = GPUAR_MAD24(l, pick, acc);
-            *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));
-        }
-        return acc;
+    GPUAR_LANE uint32_t step_last(uint32_t x, uint32_t total, uint32_t onto = 0) { return account<0, false>(paths_of_symbol(x), total, 0u, onto); }
+    GPUAR_LANE uint32_t step_last_tag(uint32_t x_tag, uint32_t total, uint32_t onto = 0) {
+        return account<static_cast<int>(kRowShift), false>(paths_of_tag(x_tag), total, 0u, onto);
     }
 
     // `onto`: what the sums are added to (the other modeler's part, when this one runs behind it)
     GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next, uint32_t onto = 0) {
-        const uint32_t xn = tree.tag(x_next);
-        const uint32_t z = GPUAR_MUL24(x, 0x10001u) + 0x10000u;   // low half: bits of x, high half: bits of x + 1
+        return account<0, true>(paths_of_symbol(x), total, tree.tag(x_next), onto);
+    }
+    // the same for a caller that has the row tags already (the low modeler of encode_kernel reads them from LDS, where the
+    // top modeler left them: no byte extraction, no shift-or, and the path bits come out of the tag by the same multiply-add)
+    GPUAR_LANE uint32_t step_tag(uint32_t x_tag, uint32_t total, uint32_t xn_tag, uint32_t onto = 0) {
+        return account<static_cast<int>(kRowShift), true>(paths_of_tag(x_tag), total, xn_tag, onto);
+    }
+
+    uint32_t next_tag;                      // row tag of the symbol whose nodes are held in left[] (the next to account)
+
+  private:
+    // z: path bits of x | path bits of x + 1, kShift bits up; kAhead: fetch the nodes of the symbol tagged xn behind the stores
+    template <int kShift, bool kAhead>
+    GPUAR_LANE uint32_t account(uint32_t z, uint32_t total, uint32_t xn, uint32_t onto) {
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24_VS((z >> 8) & 0x10000u, total, onto);  // x == 255: cumHi is the whole total
+        if (kTail) acc = GPUAR_MAD24_VS((z >> (kShift + 8)) & 0x10000u, total, onto);  // x == 255: cumHi is the whole total
         if (kHead >= 1) {
-            const uint32_t pick0 = (z >> 7) & 0x10001u;
+            const uint32_t pick0 = (z >> (kShift + 7)) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
         }
         if (kHead >= 2) {
+            static_assert(kHead < 2 || (kShift == 0 && kAhead), "depth 1 in registers: symbol-based step() only");
+            const uint32_t x = z & 0xFFu;
             const bool upper_half = x >= 128u;
             const uint32_t pick1 = (z >> 6) & 0x10001u;
             acc = GPUAR_MAD24(upper_half ? half1 : half0, pick1, acc);
@@ -313,13 +319,16 @@ struct PartialModeler {
         }
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
-            const uint32_t pick = (z >> (7 - (kFirst + k))) & 0x10001u;
+            const uint32_t pick = (z >> (kShift + 7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
             acc = GPUAR_MAD24(l, pick, acc);
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
-            where[k] = tree.node(xn, kFirst + k);
-            left[k] = *where[k];
+            if (kAhead) {
+                where[k] = tree.node(xn, kFirst + k);
+                left[k] = *where[k];
+            }
         }
+        if (kAhead) next_tag = xn;
         return acc;
     }
 };

@@ -69,11 +69,14 @@ int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
                 const uint32_t i = base + j;
                 sums[j] = top.step(in[off + i], 256u + i, i + 1 < len ? in[off + i + 1] : 0u);
             }
-            low.prime(in[off + base]);
+            // (encode_kernel's low modeler gets the symbols as row tags, the way the top modeler formed them)
+            uint32_t tags[kPhase];
+            for (uint32_t j = 0; j < count; ++j) tags[j] = low.tree.tag(in[off + base + j]) & 0xFFFFu;
+            low.prime_tag(tags[0]);
             for (uint32_t j = 0; j < count; ++j) {
                 const uint32_t i = base + j;
-                sums[j] = j + 1 < count ? low.step(in[off + i], 256u + i, in[off + i + 1], sums[j])
-                                        : low.step_last(in[off + i], 256u + i, sums[j]);
+                sums[j] = j + 1 < count ? low.step_tag(tags[j], 256u + i, tags[j + 1], sums[j])
+                                        : low.step_last_tag(tags[j], 256u + i, sums[j]);
             }
             for (uint32_t j = 0; j < count; ++j) coder.step(sums[j], kRecip.r[base + j]);
         }
