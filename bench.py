@@ -33,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--gib-per-gpu", type=float, default=8.0, help="weak scaling: GiB each GPU codes")
     ap.add_argument("--total-gib", type=float, default=8.0, help="strong scaling: GiB split over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the other-scaling pass and the gather probe may take before the line is printed without them")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=16, help="single-core CPU baseline sample")
     ap.add_argument("--no-scaling-extras", action="store_true",
@@ -557,6 +560,16 @@ def main(argv=None):
     # ---- N > 1: the OTHER scaling mode in the same run (configs[3] strong: 8 GiB over N; configs[4] weak: 8 GiB each),
     #      and the measurement behind "RCCL only if a gather is measurably cheaper than staged hipMemcpyAsync" ----
     if world > 1 and not args.no_scaling_extras:
+        # These extras must never cost the run its line: if they are not through within --extras-timeout seconds (a
+        # transport that hangs), every rank's own timer fires, rank 0 prints what the timed pass measured, and all exit.
+        def bail():
+            if rank == 0:
+                result["scaling_extras"] = f"not finished within {args.extras_timeout} s: left out"
+                print(json.dumps(result), flush=True)
+            os._exit(0 if all_ok else 1)
+        watchdog = threading.Timer(args.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         probe = gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl)
         del d_stream, d_off, P
         torch.cuda.empty_cache()
@@ -576,6 +589,7 @@ def main(argv=None):
                              else f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU"),
             }
             all_ok = all_ok and result["other_scaling"]["roundtrip_equal"]
+        watchdog.cancel()
         del Q
     else:
         del d_stream, d_off, P
@@ -602,7 +616,7 @@ def main(argv=None):
             "roundtrip_equal": bool(torch.equal(s_out, s_in)),
         }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:        # at N = 1 only: the other ranks would sit at the barrier
         result["cpu_baseline"] = cpu_baseline(args.kind, args.seed, args.cpu_sample_mib << 20)
 
     if rank == 0:
