@@ -734,13 +734,12 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_add_u32 %[a], %[lo], %[dn]\n\t" /* new lo */ \
             "v_sub_u32 %[wd], %[t1], %[dn]\n\t" /* new hi - new lo + 1 */ \
             "v_add3_u32 %[h], %[a], %[wd], -1\n\t" /* new hi */ \
+            "v_lshl_add_u32 %[t2], %[wd], 16, %[km32k]\n\t" /* (2 * width - 1) << 15: hi - lo with both one bit longer, at the top */ \
             "v_xor_b32_sdwa %[kff], %[a], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
-            "v_bfi_b32 %[t2], %[a], %[h], -1\n\t" /* ~a | h */ \
-            "v_ffbh_u32 %[e], %[kff]\n\t" /* agreeing MSBs */ \
-            "v_sub_u32 %[t3], 15, %[e]\n\t" \
-            "v_alignbit_b32 %[t2], %[t2], -1, %[t3]\n\t" \
-            "v_ffbh_u32 %[t2], %[t2]\n\t" /* underflow run */ \
-            "v_add_u32 %[n], %[e], %[t2]\n\t" \
+            "v_ffbh_u32 %[e], %[t2]\n\t" /* lane_codec.h renorm_count: n = that count - 1 + [the bounds differ at that bit] */ \
+            "v_lshlrev_b32 %[t2], %[e], %[kff]\n\t" \
+            "v_lshrrev_b32 %[t2], 31, %[t2]\n\t" \
+            "v_add3_u32 %[n], %[e], %[t2], -1\n\t" \
             "v_lshlrev_b32 %[a], %[n], %[a]\n\t" \
             "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
@@ -803,7 +802,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lx] "+v"(lx), [lma] "=&s"(lma_), [lmc] "+s"(lmc), "+v"(o0), "+v"(o1) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
@@ -818,7 +817,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
               "+v"(o0), "+v"(o1) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap) \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
@@ -869,6 +868,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // width << n.  Round 2 carried a per-symbol minimum for it; 65 million symbols of garbage never raised it.)
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u, k64k1 = 0x10001u;
+    const uint32_t minus_half = 0xFFFF8000u;               // (2 * width - 1) << 15 = (width << 16) + this: see renorm_count
     uint32_t bswap_sel, ring_wrap;
     asm volatile("s_mov_b32 %0, 0x00010203" : "=s"(bswap_sel));     // (through asm: a known constant would be spliced in as a literal)
     asm volatile("s_movk_i32 %0, 0xf00" : "=s"(ring_wrap));        // 256 * 15: the ring's dword index, scaled

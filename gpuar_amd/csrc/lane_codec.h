@@ -112,6 +112,23 @@ GPUAR_LANE uint32_t div_total(uint32_t n, Recip rc) { return GPUAR_MULHI(n, rc.m
 // zeros enter both bounds, "lo ^ hi agrees" reads as leading ones of lo ^ nh,
 // and the underflow run is the leading ones of lo & nh below bit 15.
 
+//
+// The decoder needs only n = e + u, and that is ONE count of leading zeros: write both bounds one bit longer, the
+// way the loop extends them (a1 = 2a, h1 = 2h + 1, so a1 < h1 always), d1 = h1 - a1 = 2 * wd - 1.  With r = 16 - n
+// positions left below the run, d1 = 2^r + X - Y (X, Y: what h1 and a1 hold there, X - Y > -2^(r-1) because the
+// position behind the run is not another underflow position), so d1's top bit is at r -- where a1 and h1 differ (the
+// run's last position, or the first differing one) -- or at r - 1, where they do not:
+//     n = clz17(d1) - 1 + [a1 and h1 differ at d1's top bit].
+// renorm_count() is that in 32-bit registers: d1 << 15 and (a ^ h) << 16 | 0xFFFF put both 17-bit numbers at the top.
+// Checked against the loop for every a <= h < 65536 (tests/test_lane_emulation.py, emu_check_renorm_count).
+GPUAR_LANE uint32_t renorm_count(uint32_t a, uint32_t wd) {
+    const uint32_t h = a + wd - 1u;
+    const uint32_t d1 = (wd << 16) - 0x8000u;                     // (2 * wd - 1) << 15, never 0 (wd >= 1)
+    const uint32_t differ = (((a ^ h) & 0xFFFFu) << 16) | 0xFFFFu;  // (a1 ^ h1) << 15, ones behind it
+    const uint32_t c = GPUAR_CLZ32_NZ(d1);
+    return c + ((differ << (c & 31u)) >> 31) - 1u;
+}
+
 GPUAR_LANE uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 // typed accesses to addresses that are suitably aligned by construction
@@ -829,13 +846,8 @@ struct DecoderLane {
         const uint32_t up = div_total(num_hi, rc);
         const uint32_t a = lo + dn;                           // new lo
         const uint32_t wd = up - dn;                          // new hi - new lo + 1
-        const uint32_t h = a + wd - 1u;                       // new hi
-        // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32)
-        const uint32_t e = GPUAR_CLZ32((((a ^ h) & 0xFFFFu) << 16) | 0xFFFFu);
-        // leading ones of (a & ~h) below the e agreeing bits and the first differing one, counted
-        // as the leading zeros of its complement shifted up with ones behind it
-        const uint32_t u = GPUAR_CLZ32(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
-        const uint32_t n = e + u;                             // <= 31 fresh bits
+        // e agreeing MSBs leave, then a run of u underflow positions; only their sum matters here (see above bswap32)
+        const uint32_t n = renorm_count(a, wd);               // <= 31 fresh bits
         lo = (a << n) & 0x7FFFu;
         range = wd << n;
         off = static_cast<uint32_t>((((static_cast<uint64_t>(off - dn) << 32) | peek()) << n) >> 32);

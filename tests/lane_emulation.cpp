@@ -161,6 +161,39 @@ int emu_decode_stream(const uint8_t *stream, const uint64_t *pkt_offsets, size_t
     return bad;
 }
 
+// renorm_count(a, wd) against the reference's renormalisation loop (writeEncodedBits :321-367 / readEncodedBits :787-836:
+// shift while the top bits agree, or while lo = 01.. and hi = 10..), for every a and every `stride`-th h >= a plus the
+// neighbours of a and of 0xFFFF.  stride 1 = all 2^31 pairs (8 s).  Returns the number of mismatches.
+uint64_t emu_check_renorm_count(uint32_t stride)
+{
+    uint64_t wrong = 0;
+    auto by_loop = [](uint32_t a, uint32_t h) {
+        uint16_t lo = static_cast<uint16_t>(a), hi = static_cast<uint16_t>(h);
+        uint32_t n = 0;
+        for (;;) {
+            if (((hi ^ lo) & 0x8000u) == 0) {
+            } else if ((lo & 0x4000u) && !(hi & 0x4000u)) {
+                lo &= 0x3FFFu;
+                hi |= 0x4000u;
+            } else {
+                return n;
+            }
+            lo = static_cast<uint16_t>(lo << 1);
+            hi = static_cast<uint16_t>((hi << 1) | 1u);
+            ++n;
+        }
+    };
+    for (uint32_t a = 0; a < 65536u; ++a) {
+        for (uint32_t h = a; h < 65536u; h += stride) wrong += renorm_count(a, h - a + 1u) != by_loop(a, h);
+        for (uint32_t h = a; h < 65536u && h < a + 4u; ++h) wrong += renorm_count(a, h - a + 1u) != by_loop(a, h);
+        for (uint32_t h = 65535u; h >= a && h + 4u > 65535u; --h) {
+            wrong += renorm_count(a, h - a + 1u) != by_loop(a, h);
+            if (h == 0) break;
+        }
+    }
+    return wrong;
+}
+
 // Check of the reciprocal table: for every total d, the multiple boundaries
 // k*d-1 and k*d (stepping k by `stride`) plus the largest numerator
 // d*65536-1.  Returns the number of mismatches.

@@ -43,6 +43,8 @@ def emu():
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
     lib.emu_check_recip.argtypes = [C.c_uint32]
+    lib.emu_check_renorm_count.restype = C.c_uint64
+    lib.emu_check_renorm_count.argtypes = [C.c_uint32]
     return lib
 
 
@@ -109,6 +111,12 @@ def test_latency_mode_roles_give_the_same_slots(emu, c):
     got = np.zeros_like(want)
     assert emu.emu_encode_slots_split(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov
     assert np.array_equal(got, want)
+
+
+def test_renormalisation_count_in_one_clz_equals_the_loop(emu):
+    """The decoder's n = e + u from ONE count of leading zeros (lane_codec.h renorm_count) against the reference's
+    renormalisation loop, for EVERY pair lo <= hi < 65536 (2^31 pairs, a few seconds of C)."""
+    assert emu.emu_check_renorm_count(1) == 0
 
 
 def test_reciprocal_table_is_exact(emu):
