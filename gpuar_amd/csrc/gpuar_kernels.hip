@@ -638,9 +638,9 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // half's two dwords are gone; WAITED for, an LDS atomic is 60-440 cycles dearer than a write, tools/lat_probe.hip).
 // They use decode_wave's locals by name.
 #define GPUAR_A_HEAD \
-            "v_mad_u32_u24 %[R0], %[off], %[tot], %[tot]\n\t" \
+            "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 /* off = the low half of lo : off */ \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
-            "v_add_u32 %[R0], -1, %[R0]\n\t" /* off*total + total - 1 */ \
+            "v_add_u32 %[R0], %[totm1], %[R0]\n\t" /* off*total + total - 1 (total - 1: the previous symbol's total) */ \
             "v_sub_co_u32 %[t1], %[m0], %[R0], %[t0]\n\t" /* borrow = went left at depth 0 */ \
             "v_min_u32 %[R], %[R0], %[t1]\n\t" \
             "v_cndmask_b32 %[t2], %[h1], %[h0], %[m0]\n\t" /* the depth-1 node on the path */ \
@@ -731,17 +731,20 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_mul_hi_u32 %[t1], %[t1], %[mul]\n\t" \
             "v_lshrrev_b32 %[dn], %[shift], %[dn]\n\t" \
             "v_lshrrev_b32 %[t1], %[shift], %[t1]\n\t" \
-            "v_add_u32 %[a], %[lo], %[dn]\n\t" /* new lo */ \
+            "v_mad_u32_u24 v217, %[dn], %[kffff], v217\n\t" /* lo : off -> (lo + dn) : (off - dn) in one: + dn * 0xFFFF (dn <= off, lo + dn < 2^16) */ \
             "v_sub_u32 %[wd], %[t1], %[dn]\n\t" /* new hi - new lo + 1 */ \
-            "v_add3_u32 %[h], %[a], %[wd], -1\n\t" /* new hi */ \
-            "v_lshl_add_u32 %[t2], %[wd], 16, %[km32k]\n\t" /* (2 * width - 1) << 15: hi - lo with both one bit longer, at the top */ \
-            "v_xor_b32_sdwa %[kff], %[a], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+            "v_lshl_add_u32 %[t2], %[wd], 16, %[km32k]\n\t" /* (2 * width - 1) << 15: hi - lo with both one bit longer, at the top; its high half is width - 1 */ \
+         /* (gfx950: a result written into HALF a register -- SDWA dst_sel -- may be read by the second instruction behind \
+            its producer at the earliest; the assembler does not pad hand-written text, so the order below keeps that distance) */ \
+            "v_add_u32_sdwa %[h], v217, %[t2] dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" /* new hi (high half) */ \
             "v_ffbh_u32 %[e], %[t2]\n\t" /* lane_codec.h renorm_count: n = that count - 1 + [the bounds differ at that bit] */ \
+            "v_xor_b32_sdwa %[kff], v217, %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+
+// (between the two halves of the renormalisation: the increments of the low half, GPUAR_BC_TAIL_*)
+#define GPUAR_BC_LOW_END \
             "v_lshlrev_b32 %[t2], %[e], %[kff]\n\t" \
             "v_lshrrev_b32 %[t2], 31, %[t2]\n\t" \
             "v_add3_u32 %[n], %[e], %[t2], -1\n\t" \
-            "v_lshlrev_b32 %[a], %[n], %[a]\n\t" \
-            "v_and_b32 %[lo], 0x7fff, %[a]\n\t" \
             "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
 
 #define GPUAR_BC_TAIL_CARRIED \
@@ -775,22 +778,25 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "s_or_b64 exec, exec, %[sx]\n\t" \
             "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t" /* the next 32 stream bits */
 
-// off' = ((off - dn) : window) << n, upper half (off lives in v217, the window in v216)
+// lo' : off' = (((lo + dn) : (off - dn)) : window) << n, upper half, with lo's top bit cleared: ONE 64-bit shift moves both
+// (v217 = lo << 16 | off, the window in v216).  What leaves lo at the top falls off the register; (off - dn + 1) << n
+// <= width << n = range' <= 2^16 keeps the lower half inside its 16 bits; bit 31 is the last underflow position
+// (lo' = (a << n) & 0x7FFF).
 #define GPUAR_OFF_TEXT \
-            "v_sub_u32 v217, v217, %[dn]\n\t" \
-            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t"
+            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t" \
+            "v_and_b32 v217, 0x7fffffff, v217\n\t"
 
 #define GPUAR_STEP_OPERANDS_COMMON \
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
               [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), \
               [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
-              [lo] "+v"(dec.lo), [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [oaddr] "+v"(oaddr), \
+              [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [oaddr] "+v"(oaddr), \
               [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), [n] "+v"(nbits), \
               [dn] "=&v"(dn), [bw] "=&v"(bw), [cc] "=&v"(cc), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), \
-              [a] "=&v"(a), [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
+              [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
 
 #define GPUAR_STEP_LOCALS \
-        uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, a, wd, h, e; \
+        uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx;
 
 #define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
@@ -798,11 +804,11 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         GPUAR_STEP_LOCALS \
         uint32_t lbw_, lcc_; \
         unsigned long long lma_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_CARRIED \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_TAIL_CARRIED GPUAR_BC_LOW_END GPUAR_OFF_TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lx] "+v"(lx), [lma] "=&s"(lma_), [lmc] "+s"(lmc), "+v"(o0), "+v"(o1) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half) \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [totm1] "s"((K_TOTAL) - 1u) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
@@ -812,12 +818,12 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         GPUAR_STEP_LOCALS \
         uint32_t lbw_, lcc_; \
         unsigned long long lma_, lmc_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_OFF_TEXT GPUAR_BC_TAIL_PLAIN \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_TAIL_PLAIN GPUAR_BC_LOW_END GPUAR_OFF_TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
               "+v"(o0), "+v"(o1) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half) \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [totm1] "s"((K_TOTAL) - 1u) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
         NP_OUT = np; \
     }
@@ -855,8 +861,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     }
     register uint32_t o0 asm("v204");          // the increments the previous symbol's low half still has to take (v204:v205)
     register uint32_t o1 asm("v205");
-    register uint32_t offr asm("v217");        // code - lo; v216:v217 is the pair the 64-bit shift of the window works on
-    offr = dec.off;
+    register uint32_t offr asm("v217");        // lo << 16 | (code - lo): v216:v217 is the pair the 64-bit shift works on, and
+    offr = dec.off | (dec.lo << 16);           // lower bound and code offset move through the step as ONE register
     uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
     const uint32_t col_low_lds = col_lds + SubtreeModel<9>::kLowBase;               // ... and of its first low half
     uint32_t oaddr = col_lds + dec.model.owed.at;                                   // where the half owed goes
@@ -869,7 +875,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     uint32_t kff = 0xFFFFu;                    // low half stays 0xFFFF, high half is scratch of the renormalisation
     const uint32_t k64k = 0x10000u, k64k1 = 0x10001u;
     const uint32_t minus_half = 0xFFFF8000u;               // (2 * width - 1) << 15 = (width << 16) + this: see renorm_count
-    uint32_t bswap_sel, ring_wrap;
+    uint32_t bswap_sel, ring_wrap, low_half;
+    asm volatile("s_mov_b32 %0, 0xffff" : "=s"(low_half));
     asm volatile("s_mov_b32 %0, 0x00010203" : "=s"(bswap_sel));     // (through asm: a known constant would be spliced in as a literal)
     asm volatile("s_movk_i32 %0, 0xf00" : "=s"(ring_wrap));        // 256 * 15: the ring's dword index, scaled
 
@@ -1016,7 +1023,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // (and a piece the last ring phase asked for may still be on its way into v220-v223)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(dec.ahead), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
     dec.next = (next64 >> 6) - skew16;
-    dec.off = offr;
+    dec.off = offr & 0xFFFFu;
+    dec.lo = offr >> 16;
     dec.owed_bits = nbits;
     // the increment still owed goes in now; what the plain step is then handed as "owed" is a rewrite of that half with
     // the values it holds (its write_back stores, it does not add)

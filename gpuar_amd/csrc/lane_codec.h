@@ -27,6 +27,11 @@
 // ((a ^ b) << 16) | 0xFFFF in ONE instruction: the xor lands in the high half of a register whose low half
 // is preset to 0xFFFF (kff must hold 0xFFFF in its low half; its high half is scratch)
 #define GPUAR_XOR_HI(kff, a, b) ([](uint32_t &k_, uint32_t a_, uint32_t b_) { asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(k_) : "v"(a_), "v"(b_)); return k_; }((kff), (a), (b)))
+// e = clz(GPUAR_XOR_HI(kff, a, h)) and span = ~a | h as ONE statement.  gfx950 forwards a result written into HALF a
+// register (SDWA dst_sel) to the second instruction behind its producer at the earliest; the compiler pads its own code for
+// that but cannot see into an asm statement, so the count is not left for it to place: the other bit-wise term of the
+// renormalisation sits between the two.
+#define GPUAR_AGREE_COUNT(kff, a, h, span) ([](uint32_t &k_, uint32_t a_, uint32_t h_, uint32_t &s_) { uint32_t e_; asm("v_xor_b32_sdwa %0, %3, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\tv_bfi_b32 %1, %3, %4, -1\n\tv_ffbh_u32 %2, %0" : "+v"(k_), "=&v"(s_), "=&v"(e_) : "v"(a_), "v"(h_)); return e_; }((kff), (a), (h), (span)))
 // bit-field mask ((1 << w) - 1) << off, w and off taken mod 32: one instruction
 #define GPUAR_BFM(w, off) ([](uint32_t w_, uint32_t o_) { uint32_t r_; asm("v_bfm_b32 %0, %1, %2" : "=v"(r_) : "v"(w_), "v"(o_)); return r_; }((w), (off)))
 // the same where hipcc cannot see the 24-bit bound by itself (it would emit and + v_mul_lo_u32)
@@ -51,6 +56,7 @@
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
 #define GPUAR_CLZ32_NZ(x) static_cast<uint32_t>(__builtin_clz(x))
 #define GPUAR_XOR_HI(kff, a, b) ((((a) ^ (b)) << 16) | 0xFFFFu)
+#define GPUAR_AGREE_COUNT(kff, a, h, span) ((span) = ~(a) | (h), static_cast<uint32_t>(__builtin_clz(((((a) ^ (h)) << 16) | 0xFFFFu))))
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
 #define GPUAR_MUL24_VV(a, b) ((a) * (b))
@@ -456,8 +462,9 @@ struct CoderLane {
         const uint32_t h = a + wd - 1u;                       // new hi (<= 0xFFFF: the interval only ever shrinks)
         // e agreeing MSBs leave, then a run of u underflow positions (closed form, see above bswap32);
         // neither argument of the two counts can be 0 (ones are shifted in behind the bits that matter)
-        const uint32_t e = GPUAR_CLZ32_NZ(GPUAR_XOR_HI(kff, a, h));
-        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        uint32_t span;                                        // ~a | h
+        const uint32_t e = GPUAR_AGREE_COUNT(kff, a, h, span);
+        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(span, 0xFFFFFFFFu, 15u - e));
         const uint32_t shift = e + u;
         lo = (a << shift) & 0x7FFFu;
         range = wd << shift;
@@ -524,8 +531,9 @@ struct IntervalLane {
         const uint32_t a = lo + dn;
         const uint32_t wd = up - dn;
         const uint32_t h = a + wd - 1u;
-        const uint32_t e = GPUAR_CLZ32_NZ(GPUAR_XOR_HI(kff, a, h));
-        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(~a | h, 0xFFFFFFFFu, 15u - e));
+        uint32_t span;                                        // ~a | h
+        const uint32_t e = GPUAR_AGREE_COUNT(kff, a, h, span);
+        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(span, 0xFFFFFFFFu, 15u - e));
         const uint32_t shift = e + u;
         const uint32_t moved = a << shift;
         lo = moved & 0x7FFFu;
