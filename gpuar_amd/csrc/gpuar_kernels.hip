@@ -625,18 +625,15 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #define GPUAR_SDWA_W1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
 #define GPUAR_SDWA_HALVES " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
 
-// One symbol of the hand-scheduled decoder (see above), in text pieces.  Two variants are assembled from them:
-//   CARRIED  for wavefronts whose 64 packets all own the block (uniform control flow): the increments of a symbol's
-//            low half are completed by the NEXT symbol's step, in the shadow of its first LDS read, from what this
-//            step leaves behind (v204: the count/child increment, lx and the lane mask lmc: the grandchild's) --
-//            lane masks can only be carried from one statement to the next in scalar registers where the compiler
-//            sees uniform control flow;
-//   PLAIN    for the one wavefront of a file that holds its short last packet (lanes drop out under `if`):
-//            the step forms the whole 64-bit increment itself, in v204:v205.
-// Either way the next step applies it with one ds_add_u64 (profiles/r03_decode_cost_attribution.txt: an LDS add costs
-// this wavefront ~20 cycles to issue, a ds_write_b64 ~28, and the four vector instructions that used to rebuild the
-// half's two dwords are gone; WAITED for, an LDS atomic is 60-440 cycles dearer than a write, tools/lat_probe.hip).
-// They use decode_wave's locals by name.
+// One symbol of the hand-scheduled decoder (see above), in text pieces.  The step forms the whole 64-bit increment of
+// its low half itself, in v204:v205, and the NEXT step applies it with one ds_add_u64 in the shadow of its first LDS read
+// (profiles/r03_decode_cost_attribution.txt: an LDS add costs this wavefront ~20 cycles to issue, a ds_write_b64 ~28, and
+// the four vector instructions that used to rebuild the half's two dwords are gone; WAITED for, an LDS atomic is 60-440
+// cycles dearer than a write, tools/lat_probe.hip).  One more instruction of a step waits for that shadow: clearing the
+// top bit of lo (an instruction behind an LDS operation's issue costs this wavefront less than one in the chain; a variant
+// that kept a select of the increment there needed a lane mask carried between statements in a scalar register).
+// The same text serves the one wavefront of a file that holds its short last packet (lanes drop out under `if`).
+// It uses decode_wave's locals by name.
 #define GPUAR_A_HEAD \
             "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 /* off = the low half of lo : off */ \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
@@ -652,15 +649,14 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
             "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
-#define GPUAR_A_SHADOW_CARRIED \
+#define GPUAR_A_SHADOW \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
-            64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left, set by that symbol's step; v205: lx if lmc, \
-            the grandchild); no field can carry into its neighbour (counts stay below 2^14) */ \
-            "v_cndmask_b32 v205, 0, %[lx], %[lmc]\n\t" \
+            64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left; v205: the grandchild's, if left there -- both \
+            formed by that symbol's step); no field can carry into its neighbour (counts stay below 2^14).  And the last \
+            instruction of the previous step's renormalisation: lo's top bit is cleared here, where it is needed next \
+            (the head above reads only the lower half of lo : off) */ \
             "ds_add_u64 %[oaddr], v[204:205]\n\t" \
-
-#define GPUAR_A_SHADOW_PLAIN \
-            "ds_add_u64 %[oaddr], v[204:205]\n\t" /* the increments of the previous symbol's low half, formed by its own step */
+            "v_and_b32 v217, 0x7fffffff, v217\n\t"
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
@@ -715,15 +711,18 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
             "v_lshl_add_u32 %[oaddr], %[np], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */ \
+         /* everything that hangs on the MIDDLE decision (vcc) comes first: the last decision's lane mask goes to vcc as well, \
+            because the instruction that files the symbol (the last one of the step) takes its carry from there */ \
             "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
             "v_cndmask_b32_sdwa %[ps], %[ps], %[lbw], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* symbols under the chosen grandchild node */ \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
-            "v_sub_co_u32 %[t1], %[lmc], %[R], %[pc]\n\t" \
+            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" /* the increments of the low half -> v204:v205 (added in the next step's shadow) */ \
+            "v_cndmask_b32 %[ti], 1, %[k64k], vcc\n\t" \
+            "v_sub_co_u32 %[t1], vcc, %[R], %[pc]\n\t" \
             "v_sub_u32 %[t3], %[ps], %[t2]\n\t" /* the right leaf */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[t2], %[lmc]\n\t" /* cnt(symbol) */ \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lmc]\n\t" /* all eight complemented symbol bits */ \
+            "v_cndmask_b32 %[t3], %[t3], %[t2], vcc\n\t" /* cnt(symbol) */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_mad_u32_u24 %[t1], %[t3], %[rng], %[t0]\n\t" /* cumHi * range = cumLo * range + cnt * range */ \
@@ -740,23 +739,20 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_ffbh_u32 %[e], %[t2]\n\t" /* lane_codec.h renorm_count: n = that count - 1 + [the bounds differ at that bit] */ \
             "v_xor_b32_sdwa %[kff], v217, %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n\t"
 
-// (between the two halves of the renormalisation: the increments of the low half, GPUAR_BC_TAIL_*)
+// The end of the step: the grandchild's increment sits between the SDWA write of kff and its reader; the LAST instruction
+// files the symbol: all eight complemented path bits = 2 * (the first seven) + the last decision's borrow, written
+// straight into byte J of the output word (SDWA dst_sel, the other bytes preserved) -- no shift-or per symbol
+// (GPUAR_FILE_SYMBOL, in front of the 64-bit shift).
 #define GPUAR_BC_LOW_END \
+            "v_cndmask_b32 v205, 0, %[ti], vcc\n\t" \
             "v_lshlrev_b32 %[t2], %[e], %[kff]\n\t" \
             "v_lshrrev_b32 %[t2], 31, %[t2]\n\t" \
             "v_add3_u32 %[n], %[e], %[t2], -1\n\t" \
-            "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t" \
-
-#define GPUAR_BC_TAIL_CARRIED \
-         /* ---- what the next step adds to this low half (in the shadow of its first read) */ \
-            "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
-            "v_cndmask_b32 %[lx], 1, %[k64k], vcc\n\t" \
-
-#define GPUAR_BC_TAIL_PLAIN \
-         /* ---- the increments of the low half -> v204:v205 (added by the next step) */ \
-            "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" \
-            "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
-            "v_cndmask_b32 v205, 0, %[t2], %[lmc]\n\t"
+            "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t"
+// (not the statement's very last instruction: what reads the word behind the statement is the compiler's, and it does
+// not know that the word was written by halves)
+#define GPUAR_FILE_SYMBOL(J) \
+            "v_addc_co_u32_sdwa %[word], vcc, %[np], %[np], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
@@ -781,10 +777,10 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // lo' : off' = (((lo + dn) : (off - dn)) : window) << n, upper half, with lo's top bit cleared: ONE 64-bit shift moves both
 // (v217 = lo << 16 | off, the window in v216).  What leaves lo at the top falls off the register; (off - dn + 1) << n
 // <= width << n = range' <= 2^16 keeps the lower half inside its 16 bits; bit 31 is the last underflow position
-// (lo' = (a << n) & 0x7FFF).
+// (lo' = (a << n) & 0x7FFF) and is cleared in the NEXT step's LDS shadow (GPUAR_A_SHADOW; decode_wave clears it once
+// more behind the last step).
 #define GPUAR_OFF_TEXT \
-            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t" \
-            "v_and_b32 v217, 0x7fffffff, v217\n\t"
+            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t"
 
 #define GPUAR_STEP_OPERANDS_COMMON \
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
@@ -799,33 +795,17 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx;
 
-#define GPUAR_DECODE_SYMBOL_CARRIED(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
+#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_MUL, K_SHIFT, WORD, J) \
     { \
         GPUAR_STEP_LOCALS \
-        uint32_t lbw_, lcc_; \
+        uint32_t lbw_, lcc_, ti_; \
         unsigned long long lma_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_CARRIED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_TAIL_CARRIED GPUAR_BC_LOW_END GPUAR_OFF_TEXT \
+        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lx] "+v"(lx), [lma] "=&s"(lma_), [lmc] "+s"(lmc), "+v"(o0), "+v"(o1) \
+              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1) \
             : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
               [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [totm1] "s"((K_TOTAL) - 1u) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
-        NP_OUT = np; \
-    }
-
-#define GPUAR_DECODE_SYMBOL_PLAIN(K_TOTAL, K_MUL, K_SHIFT, NP_OUT) \
-    { \
-        GPUAR_STEP_LOCALS \
-        uint32_t lbw_, lcc_; \
-        unsigned long long lma_, lmc_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_TAIL_PLAIN GPUAR_BC_LOW_END GPUAR_OFF_TEXT \
-            : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [lma] "=&s"(lma_), [lmc] "=&s"(lmc_), \
-              "+v"(o0), "+v"(o1) \
-            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [totm1] "s"((K_TOTAL) - 1u) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
-        NP_OUT = np; \
     }
 
 // LDS of a decoder workgroup (one wavefront): the 64 models and the 64 stream rings, 40 KiB -> four per CU.
@@ -966,24 +946,25 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 // i + j is 256 + i + j with i a multiple of 64: the total itself selects lane j (no separate index to count up).
 #define GPUAR_MUL_OF(TOTAL) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(TOTAL)))
 #define GPUAR_SHIFT_OF(J) block_shift   /* the same for all 64 symbols of a block, see RecipTable */
-#define GPUAR_DECODE_BLOCK(SYMBOL)                                                                                   \
+#define GPUAR_DECODE_BLOCK                                                                                           \
     {                                                                                                                \
-        uint32_t block[16];                                                                                          \
+        uint32_t block[16], word;                                                                                    \
+        asm volatile("v_mov_b32 %0, 0" : "=v"(word));   /* (defined before the first byte goes in) */                \
         const uint32_t block_shift = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.shift), 0)); \
         _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 2u) {                                                 \
             const uint32_t j0 = 4u * g; /* wave-uniform: first symbol of this run inside the block */               \
             const uint32_t total0 = 256u + i + j0;                                                                   \
-            uint32_t word, np_out;                                                                                   \
-            SYMBOL(total0, GPUAR_MUL_OF(total0), GPUAR_SHIFT_OF(j0), np_out) word = np_out;                              \
-            SYMBOL(total0 + 1u, GPUAR_MUL_OF(total0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), np_out) word |= np_out << 8;         \
-            SYMBOL(total0 + 2u, GPUAR_MUL_OF(total0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), np_out) word |= np_out << 16;        \
-            SYMBOL(total0 + 3u, GPUAR_MUL_OF(total0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), np_out) word |= np_out << 24;        \
-            block[g] = ~word; /* np holds the COMPLEMENTED symbol bits */                                            \
+            /* every step writes its symbol into its own byte of the word (the step's last instruction) */              \
+            GPUAR_DECODE_SYMBOL(total0, GPUAR_MUL_OF(total0), GPUAR_SHIFT_OF(j0), word, 0)                               \
+            GPUAR_DECODE_SYMBOL(total0 + 1u, GPUAR_MUL_OF(total0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), word, 1)                \
+            GPUAR_DECODE_SYMBOL(total0 + 2u, GPUAR_MUL_OF(total0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), word, 2)                \
+            GPUAR_DECODE_SYMBOL(total0 + 3u, GPUAR_MUL_OF(total0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), word, 3)                \
+            block[g] = ~word; /* the path bits are the COMPLEMENTED symbol bits */                                   \
             GPUAR_RING_PHASE                                                                                         \
-            SYMBOL(total0 + 4u, GPUAR_MUL_OF(total0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), np_out) word = np_out;               \
-            SYMBOL(total0 + 5u, GPUAR_MUL_OF(total0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), np_out) word |= np_out << 8;         \
-            SYMBOL(total0 + 6u, GPUAR_MUL_OF(total0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), np_out) word |= np_out << 16;        \
-            SYMBOL(total0 + 7u, GPUAR_MUL_OF(total0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), np_out) word |= np_out << 24;        \
+            GPUAR_DECODE_SYMBOL(total0 + 4u, GPUAR_MUL_OF(total0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), word, 0)                \
+            GPUAR_DECODE_SYMBOL(total0 + 5u, GPUAR_MUL_OF(total0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), word, 1)                \
+            GPUAR_DECODE_SYMBOL(total0 + 6u, GPUAR_MUL_OF(total0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), word, 2)                \
+            GPUAR_DECODE_SYMBOL(total0 + 7u, GPUAR_MUL_OF(total0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), word, 3)                \
             block[g + 1u] = ~word;                                                                                   \
             GPUAR_RING_PHASE                                                                                         \
         }                                                                                                            \
@@ -992,27 +973,21 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);                 \
     }
 
-    // ---- blocks that every lane of the wavefront owns: uniform control flow, CARRIED variant ----
+    // ---- blocks that every lane of the wavefront owns: uniform control flow ----
     const uint32_t len_min = wave_max(~dec.ulen) ^ 0xFFFFFFFFu;
-    {
-        // v204:v205 = the 64-bit increment the previous symbol's low half still has to take (added in the shadow of the
-        // next step's first read); nothing is owed yet: an add of zero to the half reset() named.
-        // (Initial values go through asm: a known constant would be spliced into the statements as an immediate.)
-        uint32_t lx;
-        unsigned long long lmc;
-        asm volatile("s_mov_b64 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=s"(lmc), "=v"(lx), "=v"(o0), "=v"(o1));
-        for (; i + 64u <= len_min; i += 64u) {
-            GPUAR_ROTATE_RECIPS
-            GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_CARRIED)
-        }
-        // the increment still owed, completed the way the step does: v204:v205 then hold what is to be added
-        asm volatile("v_cndmask_b32 v205, 0, %[lx], %[lmc]" : "+v"(o0), "+v"(o1) : [lx] "v"(lx), [lmc] "s"(lmc));
+    // v204:v205 = the 64-bit increment the previous symbol's low half still has to take (added in the shadow of the
+    // next step's first read); nothing is owed yet: an add of zero to the half reset() named.
+    // (Initial values go through asm: a known constant would be spliced into the statements as an immediate.)
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(o0), "=v"(o1));
+    for (; i + 64u <= len_min; i += 64u) {
+        GPUAR_ROTATE_RECIPS
+        GPUAR_DECODE_BLOCK
     }
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
-    //      dead lanes of the last wavefront): lanes that do not own the block sit it out, PLAIN variant ----
+    //      dead lanes of the last wavefront): lanes that do not own the block sit it out ----
     for (; i + 64u <= len_max; i += 64u) {
         GPUAR_ROTATE_RECIPS
-        if (i + 64u <= dec.ulen) GPUAR_DECODE_BLOCK(GPUAR_DECODE_SYMBOL_PLAIN)
+        if (i + 64u <= dec.ulen) GPUAR_DECODE_BLOCK
     }
 #undef GPUAR_DECODE_BLOCK
 #undef GPUAR_MUL_OF
@@ -1024,7 +999,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(dec.ahead), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
     dec.next = (next64 >> 6) - skew16;
     dec.off = offr & 0xFFFFu;
-    dec.lo = offr >> 16;
+    dec.lo = (offr >> 16) & 0x7FFFu;           // (the step leaves lo's top bit to the next step's shadow)
     dec.owed_bits = nbits;
     // the increment still owed goes in now; what the plain step is then handed as "owed" is a rewrite of that half with
     // the values it holds (its write_back stores, it does not add)
