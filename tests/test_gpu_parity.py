@@ -346,7 +346,8 @@ def test_compaction_offsets_beyond_4gib(H):
 
 def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
     """2048 packets, every one from a different source model (uniform, k-symbol, geometric, long
-    runs, ramps, near-midpoint pairs, constant): slot-for-slot equality with the oracle, then decode."""
+    runs, ramps, near-midpoint pairs, constant, constant with a few late strangers): slot-for-slot equality with the
+    oracle, then decode."""
     rng = np.random.default_rng(20261003)
     npk = 2048
     data = np.empty(npk * 8192, dtype=np.uint8)
@@ -367,6 +368,9 @@ def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
             view[:] = rng.choice(np.array([0x7F, 0x80], dtype=np.uint8), 8192)
         elif mode == 6:
             view[:] = int(rng.integers(0, 256))
+            if p % 16 == 14:        # a constant packet with a few strangers late in it: the narrowest intervals there are
+                late = rng.integers(6000, 8192, 12)      # (width 1 or 2 of a range just above 2^14, total near 2^13)
+                view[late] = rng.integers(0, 256, 12, dtype=np.uint8)
         else:
             view[:] = np.sort(rng.integers(0, 256, 8192, dtype=np.uint8))
     want, want_len, total = oracle_slots(oracle, data)
