@@ -387,6 +387,54 @@ def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
     assert H.status() == 0
 
 
+@pytest.mark.parametrize("seed", [7, 8])
+def test_round_trips_over_ten_source_models(H, oracle, seed, encode_mode):
+    """4096 packets from ten source models -- uniform, few symbols, geometric, runs, ramps, midpoint pairs, a constant with
+    1-40 strangers late in the packet (intervals of width 1-3), sorted, one dominant symbol, zipf -- through both decoders;
+    every 16th packet's stream against the reference codec."""
+    rng = np.random.default_rng(seed)
+    npk = 4096
+    data = np.empty(npk * 8192, dtype=np.uint8)
+    for p in range(npk):
+        v = data[p * 8192:(p + 1) * 8192]
+        m = p % 10
+        if m == 0:
+            v[:] = rng.integers(0, 256, 8192, dtype=np.uint8)
+        elif m == 1:
+            v[:] = rng.integers(0, int(rng.integers(1, 9)), 8192, dtype=np.uint8) * int(rng.integers(1, 32))
+        elif m == 2:
+            v[:] = (rng.geometric(float(rng.uniform(0.02, 0.5)), 8192) % 256).astype(np.uint8)
+        elif m == 3:
+            v[:] = np.repeat(rng.integers(0, 256, 8192 // 32, dtype=np.uint8), 32)
+        elif m == 4:
+            v[:] = (np.arange(8192) * int(rng.integers(1, 255))) % 256
+        elif m == 5:
+            v[:] = rng.choice(np.array([0x7F, 0x80], dtype=np.uint8), 8192)
+        elif m == 6:
+            v[:] = int(rng.integers(0, 256))
+            late = rng.integers(4000, 8192, int(rng.integers(1, 40)))
+            v[late] = rng.integers(0, 256, late.size, dtype=np.uint8)
+        elif m == 7:
+            v[:] = np.sort(rng.integers(0, 256, 8192, dtype=np.uint8))
+        elif m == 8:
+            k = int(rng.integers(2, 6))
+            v[:] = rng.choice(rng.integers(0, 256, k, dtype=np.uint8), 8192, p=np.array([0.97] + [0.03 / (k - 1)] * (k - 1)))
+        else:
+            v[:] = (rng.zipf(1.3, 8192) % 256).astype(np.uint8)
+    d_in = torch.from_numpy(data).cuda()
+    d_slots = H.encode(d_in)
+    assert H.status() == 0
+    assert torch.equal(H.decode(d_slots, npk), d_in)
+    d_stream, d_off = H.compact(d_slots, npk)
+    assert torch.equal(H.decode_stream(d_stream, d_off, npk), d_in)
+    assert H.status() == 0
+    off = d_off.cpu().numpy()
+    got = d_stream[:int(off[-1])].cpu().numpy()
+    for p in range(0, npk, 16):
+        want = oracle.encode_stream(data[p * 8192:(p + 1) * 8192])
+        assert np.array_equal(got[off[p]:off[p + 1]], want), f"packet {p} (source model {p % 10})"
+
+
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     """bench.py --gpus 2 through torch.distributed.run, both ranks on this box's one GPU (gloo control
     plane, GPUAR_OVERSUBSCRIBE_DEVICES=1): rank r codes bytes [r*B, (r+1)*B) of the stream, the JSON line
