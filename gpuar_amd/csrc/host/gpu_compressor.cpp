@@ -110,7 +110,8 @@ void sliced_io(int fd, uint8_t *buf, size_t n, uint64_t at, const char *error) {
 // cache directly (tools/io_probe.cpp: 57 GB/s, the same as from hipHostMalloc memory, with no copy on the CPU).
 // Registration costs ~15 ms per GiB and is therefore done window by window (256 MiB), by the lane that is about
 // to copy from the window, while the other lanes and the writer are already at work -- registering an 8 GiB file
-// in one go would hold the whole pipeline up for 0.12 s.  `data() == nullptr` means the file could not be mapped,
+// in one go would hold the whole pipeline up for 0.12 s.  The FIRST registration of a process costs ~35 ms whatever its
+// size: the jobs start it on a thread of its own, next to the lanes' buffer allocation (warmFirstWindow).  `data() == nullptr` means the file could not be mapped,
 // `require()` returning false that a window could not be registered: callers fall back to pread.
 class MappedInput {
   public:
@@ -143,6 +144,7 @@ class MappedInput {
         return true;
     }
     void close() {
+        if (warmer.joinable()) warmer.join();
         if (!base) return;
         for (size_t w = 0; w < state.size(); ++w)
             if (state[w]) (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
@@ -151,12 +153,21 @@ class MappedInput {
         state.clear();
         refused = false;
     }
+    // registers the first window on a thread of its own (the first registration of a process costs ~35 ms, as long as a lane
+    // takes to allocate its buffers: the two then run side by side); close() waits for it
+    void warmFirstWindow(int device) {
+        if (!base) return;
+        warmer = std::thread([this, device] {
+            if (hipSetDevice(device) == hipSuccess) (void)require(0, std::min(kWindow, size));
+        });
+    }
     const uint8_t *data() const { return base; }
     // a copy must not straddle two registrations: the end of the window `at` lies in
     static size_t windowEnd(uint64_t at) { return (at / kWindow + 1) * kWindow; }
 
   private:
     static constexpr size_t kWindow = 256u << 20;
+    std::thread warmer;
     const uint8_t *base = nullptr;
     size_t size = 0;
     std::mutex lock;
@@ -496,10 +507,12 @@ struct GPUCompressor::DeviceBuffers {
 };
 
 GPUCompressor::GPUCompressor() {
+    trace("GPUCompressor: constructing (the HIP runtime starts here)");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         throw std::runtime_error("No HIP device found (use --host to run the codec on the CPU)");
     devices.push_back(0);
+    trace("GPUCompressor: devices counted");
     initConstantRange();     // kept for parity with src/gpu_compressor.cpp:19; a no-op for these kernels
 }
 
@@ -620,6 +633,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         MappedInput mapped;
         mapped.open(in_fd, info.uncompressedFileSize);
         trace(mapped.data() ? "compress: input mapped" : "compress: input NOT mapped (pread path)");
+        mapped.warmFirstWindow(devices[0]);
         // room for the worst case up front: writing into allocated blocks is faster than growing the file, and the real
         // length is set at the end (best effort: a file system without fallocate just grows the file as it goes)
         // (the fallocate system call, not posix_fallocate: where the file system cannot do it, glibc's stand-in would write zeros)
@@ -648,12 +662,15 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                             // contiguous packet ranges in file order, dealt round-robin: chunk c belongs to device c mod G
                             const size_t c = g + G * next_of_device[g].fetch_add(1);
                             if (c >= n_chunks || failure.stop) break;
+                            if (c == 0) trace("compress: lane of chunk 0 starts");
                             if (!b.cap) b.allocate(b.device, chunkPackets, true);
+                            if (c == 0) trace("compress: its buffers allocated");
                             hip_check(hipSetDevice(b.device), "hipSetDevice");
                             b.epoch = static_cast<hipEvent_t>(epochOf(g));
                             const uint64_t at = chunk_at[c];
                             const size_t n_plain = static_cast<size_t>(chunk_at[c + 1] - at);
                             b.upload(b.d_plain, mapped, in_fd, at, n_plain, "Read input file failed");
+                            if (c == 0) trace("compress: its input on its way (window registered, copy queued)");
                             uint32_t flags = 0;
                             const size_t n_stream = b.encodeChunk(n_plain, flags);
                             if (c < 3) trace("compress: kernels of an early chunk done, chunk", static_cast<double>(c));
@@ -861,6 +878,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         trace("decompress: files open, device set");
         MappedInput mapped;
         mapped.open(in_fd, fileSize);
+        mapped.warmFirstWindow(devices[0]);
         // packet lengths from the index trailer when the file has one (packet_index.hpp)
         std::vector<uint16_t> index;
         const bool indexed = PacketIndex::read(openFile, FileHeader::HEADER_LENGTH, stream_end, fileSize, index);
