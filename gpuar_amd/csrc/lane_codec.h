@@ -24,13 +24,11 @@
 #define GPUAR_CLZ32_NZ(x) static_cast<uint32_t>(__builtin_clz(x))
 #define GPUAR_MULHI(a, b) __umulhi((a), (b))
 #define GPUAR_MUL24(a, b) __umul24((a), (b))     // both factors < 2^24: one full-rate multiply
-// ((a ^ b) << 16) | 0xFFFF in ONE instruction: the xor lands in the high half of a register whose low half
-// is preset to 0xFFFF (kff must hold 0xFFFF in its low half; its high half is scratch)
-#define GPUAR_XOR_HI(kff, a, b) ([](uint32_t &k_, uint32_t a_, uint32_t b_) { asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(k_) : "v"(a_), "v"(b_)); return k_; }((kff), (a), (b)))
-// e = clz(GPUAR_XOR_HI(kff, a, h)) and span = ~a | h as ONE statement.  gfx950 forwards a result written into HALF a
-// register (SDWA dst_sel) to the second instruction behind its producer at the earliest; the compiler pads its own code for
-// that but cannot see into an asm statement, so the count is not left for it to place: the other bit-wise term of the
-// renormalisation sits between the two.
+// e = clz(((a ^ h) << 16) | 0xFFFF) and span = ~a | h as ONE statement: the xor lands in the high half of a register whose
+// low half is preset to 0xFFFF (kff: low half 0xFFFF, high half scratch), so the count needs no guard for a zero argument.
+// gfx950 forwards a result written into HALF a register (SDWA dst_sel) to the second instruction behind its producer at
+// the earliest; the compiler pads its own code for that but cannot see into an asm statement, so the count is not left
+// for it to place: the other bit-wise term of the renormalisation sits between the two.
 #define GPUAR_AGREE_COUNT(kff, a, h, span) ([](uint32_t &k_, uint32_t a_, uint32_t h_, uint32_t &s_) { uint32_t e_; asm("v_xor_b32_sdwa %0, %3, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\tv_bfi_b32 %1, %3, %4, -1\n\tv_ffbh_u32 %2, %0" : "+v"(k_), "=&v"(s_), "=&v"(e_) : "v"(a_), "v"(h_)); return e_; }((kff), (a), (h), (span)))
 // bit-field mask ((1 << w) - 1) << off, w and off taken mod 32: one instruction
 #define GPUAR_BFM(w, off) ([](uint32_t w_, uint32_t o_) { uint32_t r_; asm("v_bfm_b32 %0, %1, %2" : "=v"(r_) : "v"(w_), "v"(o_)); return r_; }((w), (off)))
@@ -55,7 +53,6 @@
 #define GPUAR_LANE inline
 #define GPUAR_CLZ32(x) ((x) ? static_cast<uint32_t>(__builtin_clz(x)) : 32u)
 #define GPUAR_CLZ32_NZ(x) static_cast<uint32_t>(__builtin_clz(x))
-#define GPUAR_XOR_HI(kff, a, b) ((((a) ^ (b)) << 16) | 0xFFFFu)
 #define GPUAR_AGREE_COUNT(kff, a, h, span) ((span) = ~(a) | (h), static_cast<uint32_t>(__builtin_clz(((((a) ^ (h)) << 16) | 0xFFFFu))))
 #define GPUAR_MULHI(a, b) static_cast<uint32_t>((static_cast<uint64_t>(a) * (b)) >> 32)
 #define GPUAR_MUL24(a, b) ((a) * (b))
@@ -379,7 +376,7 @@ struct CoderLane {
     uint32_t n;
     uint32_t at;         // offset from `base` of the next dword to store
     uint32_t last;       // offset of the last dword of the slot: stores beyond it land there
-    uint32_t kff;        // low half 0xFFFF, high half scratch (GPUAR_XOR_HI)
+    uint32_t kff;        // low half 0xFFFF, high half scratch (GPUAR_AGREE_COUNT)
     uint8_t *base;       // same pointer in every lane of a wavefront (scalar register on the GPU)
     uint32_t body_off;   // this lane's byte offset of slot + 4
 
