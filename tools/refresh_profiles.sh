@@ -39,6 +39,11 @@ others)
     ;;
 bench)
     timeout -k 10 400 python3 bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+    # the kernel statistics of that very command (a shorter run; TMPDIR for the profiler's scratch files)
+    rm -rf "gpurun_out/prof_bench_$tag"
+    ( export TMPDIR=/tmp; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/prof_bench_$tag" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 )
+    stats="$(find "gpurun_out/prof_bench_$tag" -name '*kernel_stats.csv' | head -1)"
+    [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench_kernel_stats.csv"
     for kind in text zipf; do
         timeout -k 10 200 python3 bench.py --kind "$kind" --seed 1 --gib-per-gpu 8 --no-cpu-baseline --no-small-config > "$out/${tag}_bench_$kind.json" 2>/dev/null
     done
