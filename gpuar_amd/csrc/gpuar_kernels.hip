@@ -411,6 +411,7 @@ struct EncodeSmallLds {
     uint32_t sums[kSumSlots][kSmallPhase][kLanes];    // [slot][symbol][lane], cumLo | cumHi << 16 in the making
     uint32_t bytes[kByteBufs][kSmallPhase / 4][kLanes];    // the input bytes of a phase
     uint32_t words[2][kSmallPhase][kLanes];   // IntervalLane -> SinkLane
+    uint32_t final_lo[kLanes];                // ... and, once per packet, the lower bound behind its last symbol
 };
 
 // the input bytes of one phase at in + at (a multiple of the phase length), zero beyond `len`
@@ -554,6 +555,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             }
             lds_barrier();
         }
+        lds.final_lo[lane] = interval.lo;                     // (read behind two more barriers)
         lds_barrier();
     } else {
         SinkLane sink;
@@ -577,7 +579,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         }
         if (live) {
             bool overflowed;
-            sink.finish(len, overflowed);
+            sink.finish(len, overflowed, lds.final_lo[lane]);
             if (overflowed) atomicOr(status, GPUAR_STATUS_SLOT_OVERFLOW);
         }
     }

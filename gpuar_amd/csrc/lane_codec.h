@@ -521,7 +521,9 @@ struct IntervalLane {
         range = 0x10000u;
         kff = 0xFFFFu;
     }
-    // agreed bits [15:0] | e [20:16] | u [29:24] | bit 14 of the new lo [31]
+    // agreed bits [15:0] | e [23:16] | u [31:24]: whole bytes, so that the sink's instructions pick them out of the word
+    // by operand selects (SDWA) instead of extracting them.  (The sink also needs bit 14 of the LAST lower bound, once:
+    // the kernel hands `lo` over when the packet is through.)
     GPUAR_LANE uint32_t step(uint32_t cums, Recip rc) {
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
@@ -532,18 +534,21 @@ struct IntervalLane {
         const uint32_t e = GPUAR_AGREE_COUNT(kff, a, h, span);
         const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(span, 0xFFFFFFFFu, 15u - e));
         const uint32_t shift = e + u;
-        const uint32_t moved = a << shift;
-        lo = moved & 0x7FFFu;
+        lo = (a << shift) & 0x7FFFu;
         range = wd << shift;
         const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
-        return agreed | (e << 16) | (u << 24) | ((moved << 17) & 0x80000000u);
+        return agreed | (e << 16) | (u << 24);
     }
 };
 
 struct SinkLane : CoderLane {
+    // final_lo: the interval lane's lower bound behind the packet's last symbol (finish() looks at its bit 14)
+    GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed, uint32_t final_lo) {
+        lo = final_lo;
+        return CoderLane::finish(ulen, overflowed);
+    }
     GPUAR_LANE void take(uint32_t packed) {
-        const uint32_t agreed = packed & 0xFFFFu, e = (packed >> 16) & 0x1Fu, u = (packed >> 24) & 0x3Fu;
-        lo = (packed >> 17) & 0x4000u;                         // all finish() looks at
+        const uint32_t agreed = packed & 0xFFFFu, e = (packed >> 16) & 0xFFu, u = packed >> 24;
         const uint32_t em1 = e - 1u;
         const bool shift_out = e != 0u;
         uint32_t bits = agreed + GPUAR_BFM(pending, em1);

@@ -134,7 +134,7 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
             for (uint32_t j = 0; j < count; ++j) sink.take(words[j]);
         }
         bool ov;
-        sink.finish(len, ov);
+        sink.finish(len, ov, interval.lo);
         any_overflow |= ov ? 1 : 0;
     }
     return any_overflow;

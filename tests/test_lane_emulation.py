@@ -104,7 +104,7 @@ def test_phased_modelers_give_the_same_slots(emu, c):
 @pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
 def test_latency_mode_roles_give_the_same_slots(emu, c):
     """encode_small_kernel's five roles: the tree dealt 3 + 3 + (0, 7, tail) to three modelers that add onto each
-    other, the coder cut into IntervalLane | SinkLane joined by one word per symbol (agreed bits, e, u, bit 14 of lo).
+    other, the coder cut into IntervalLane | SinkLane joined by one word per symbol (agreed bits, e, u) and the last lower bound.
     Same slots as the straight emulation -- the adversarial packet that owes 2396 underflow bits included."""
     data = np.ascontiguousarray(case_input(c))
     want, npk, ov = emu_encode(emu, data)
