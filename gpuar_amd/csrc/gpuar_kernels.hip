@@ -1273,7 +1273,8 @@ extern "C" {
 
 size_t gpuar_hip_packet_count(size_t n_bytes) { return (n_bytes + GPUAR_PACKET_BYTES - 1) / GPUAR_PACKET_BYTES; }
 
-int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream) {
+int gpuar_hip_encode_mode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream, int mode) {
+    if (mode != GPUAR_MODE_AUTO && mode != GPUAR_MODE_THROUGHPUT && mode != GPUAR_MODE_LATENCY) return GPUAR_ERR_ARGUMENT;
     if (n_bytes == 0) return GPUAR_OK;
     if (!d_in || !d_slots) return GPUAR_ERR_ARGUMENT;
     if (!aligned16(d_in) || !aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_status) & 3u)) return GPUAR_ERR_ALIGNMENT;
@@ -1282,14 +1283,10 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint
     const size_t n_packets = gpuar_hip_packet_count(n_bytes);
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t groups = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
-    // Small inputs cannot fill the chip and take as long as one packet: they go to the latency-mode kernel (five
-    // roles, a shorter step).  GPUAR_ENCODE_MODE=throughput|latency pins the choice (tests run both on the same
-    // inputs; the slots are the same bytes either way).
-    bool latency = groups <= gpuar::kSmallGroups;
-    if (const char *mode = getenv("GPUAR_ENCODE_MODE")) {
-        if (!strcmp(mode, "throughput")) latency = false;
-        if (!strcmp(mode, "latency")) latency = true;
-    }
+    // Small inputs cannot fill the chip and take as long as one packet: left to itself (GPUAR_MODE_AUTO) such a launch
+    // goes to the latency-mode kernel (six roles, a shorter step).  The slots are the same bytes either way; the
+    // caller's `mode` is the only switch (no environment is read here).
+    const bool latency = mode == GPUAR_MODE_LATENCY || (mode == GPUAR_MODE_AUTO && groups <= gpuar::kSmallGroups);
     if (latency) {
         gpuar::encode_small_kernel<<<groups, 6 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
             d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
@@ -1299,6 +1296,10 @@ int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint
     gpuar::encode_kernel<<<blocks, 4 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
         d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
     return check_launch();
+}
+
+int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream) {
+    return gpuar_hip_encode_mode(d_in, n_bytes, d_slots, d_status, stream, GPUAR_MODE_AUTO);
 }
 
 // n_bytes: how much of d_slots may be read (n_packets * 8704, or less when the last slot is a partial one)
@@ -1381,7 +1382,9 @@ const char *gpuar_hip_error_string(int code) {
     }
 }
 
-const char *gpuar_hip_version(void) { return "gpuar-hip 0.1 gfx950"; }
+const char *gpuar_hip_version(void) { return "gpuar-hip 0.2 gfx950"; }
+
+int gpuar_hip_abi_version(void) { return GPUAR_HIP_ABI_VERSION; }
 
 int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8_t *d_out, void *stream) {
     if (n == 0) return GPUAR_OK;

@@ -477,11 +477,12 @@ struct GPUCompressor::DeviceBuffers {
     // d_plain[0..n_plain) -> d_stream[0..n_stream), h_offsets[0..n_packets]; returns n_stream and, through `flags`,
     // what THIS chunk's launches reported (GPUAR_STATUS_*): the status word travels back with the offsets, on the
     // lane's own stream -- no device-wide synchronisation, no flag shared with another lane
-    size_t encodeChunk(size_t n_plain, uint32_t &flags) {
+    // `mode`: GPUAR_MODE_* -- which encode kernel (the caller knows whether this launch has the chip to itself)
+    size_t encodeChunk(size_t n_plain, uint32_t &flags, int mode) {
         const size_t n_packets = (n_plain + kPacket - 1) / kPacket;
         hip_check(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream), "memset");
         hip_check(hipEventRecord(t0, stream), "event");
-        gpuar_check(gpuar_hip_encode(d_plain, n_plain, d_slots, d_status, stream), "gpuar_hip_encode");
+        gpuar_check(gpuar_hip_encode_mode(d_plain, n_plain, d_slots, d_status, stream, mode), "gpuar_hip_encode_mode");
         gpuar_check(gpuar_hip_compact(d_slots, n_packets, d_stream, d_offsets, stream), "gpuar_hip_compact");
         hip_check(hipEventRecord(t1, stream), "event");
         hip_check(hipMemcpyAsync(h_offsets, d_offsets, (n_packets + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "D2H");
@@ -627,6 +628,10 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         for (uint64_t at = 0; at < info.uncompressedFileSize; at += rampPackets(chunk_at.size() - 1, chunkPackets) * kPacket) chunk_at.push_back(at);
         const size_t n_chunks = chunk_at.size();
         chunk_at.push_back(info.uncompressedFileSize);
+        // The latency-mode encode kernel is faster only for a launch that has the chip to itself (include/gpuar_hip.h):
+        // a job of one chunk.  With several chunks the lanes of a device keep three launches in flight (the ramped first
+        // chunks are small enough for GPUAR_MODE_AUTO to pick the latency kernel), so the pipeline names the kernel itself.
+        const int encode_mode = n_chunks == 1 ? GPUAR_MODE_AUTO : GPUAR_MODE_THROUGHPUT;
         const int in_fd = fileno(openFile);
         hip_check(hipSetDevice(devices[0]), "hipSetDevice");
         trace("compress: files open, device set");
@@ -672,7 +677,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                             b.upload(b.d_plain, mapped, in_fd, at, n_plain, "Read input file failed");
                             if (c == 0) trace("compress: its input on its way (window registered, copy queued)");
                             uint32_t flags = 0;
-                            const size_t n_stream = b.encodeChunk(n_plain, flags);
+                            const size_t n_stream = b.encodeChunk(n_plain, flags, encode_mode);
                             if (c < 3) trace("compress: kernels of an early chunk done, chunk", static_cast<double>(c));
                             if (flags & GPUAR_STATUS_SLOT_OVERFLOW)
                                 throw std::runtime_error("a packet outgrew its 8704-byte slot (input bytes " + std::to_string(at) + " .. " +

@@ -20,10 +20,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgpuar_hip.so")
 EXPORTS = [
     "initConstantRange", "garCompressExecutor", "garDecompressExecutor",
-    "gpuar_hip_packet_count", "gpuar_hip_encode", "gpuar_hip_decode", "gpuar_hip_compact",
+    "gpuar_hip_packet_count", "gpuar_hip_encode", "gpuar_hip_encode_mode", "gpuar_hip_decode", "gpuar_hip_compact",
     "gpuar_hip_decode_stream", "gpuar_hip_status", "gpuar_hip_last_error", "gpuar_hip_error_string",
-    "gpuar_hip_version", "gpuar_hip_generate",
+    "gpuar_hip_version", "gpuar_hip_abi_version", "gpuar_hip_generate",
 ]
+ABI_VERSION = 2                      # GPUAR_HIP_ABI_VERSION of the header these bindings were written against
+MODE_ID = {"auto": 0, "throughput": 1, "latency": 2}     # GPUAR_MODE_*
 
 _lib = None
 
@@ -52,6 +54,8 @@ def load() -> C.CDLL:
     lib.gpuar_hip_packet_count.argtypes = [sz]
     lib.gpuar_hip_encode.restype = C.c_int
     lib.gpuar_hip_encode.argtypes = [vp, sz, vp, vp, vp]
+    lib.gpuar_hip_encode_mode.restype = C.c_int
+    lib.gpuar_hip_encode_mode.argtypes = [vp, sz, vp, vp, vp, C.c_int]
     lib.gpuar_hip_decode.restype = C.c_int
     lib.gpuar_hip_decode.argtypes = [vp, sz, vp, vp, vp]
     lib.gpuar_hip_compact.restype = C.c_int
@@ -66,10 +70,24 @@ def load() -> C.CDLL:
     lib.gpuar_hip_error_string.argtypes = [C.c_int]
     lib.gpuar_hip_version.restype = C.c_char_p
     lib.gpuar_hip_version.argtypes = []
+    lib.gpuar_hip_abi_version.restype = C.c_int
+    lib.gpuar_hip_abi_version.argtypes = []
     lib.gpuar_hip_generate.restype = C.c_int
     lib.gpuar_hip_generate.argtypes = [C.c_int, C.c_uint64, C.c_uint64, sz, vp, vp]
+    if lib.gpuar_hip_abi_version() != ABI_VERSION:
+        raise GpuarError(f"{LIB_PATH} speaks ABI {lib.gpuar_hip_abi_version()}, these bindings {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
+
+
+def _mode_id(mode, env_var) -> int:
+    """GPUAR_MODE_* for a call: the caller's `mode` ("auto" | "throughput" | "latency"), else the environment variable
+    that tests and tools use to pin a kernel (GPUAR_ENCODE_MODE / GPUAR_DECODE_MODE) -- read HERE, in the Python shim,
+    never inside the library --, else auto."""
+    name = mode if mode is not None else os.environ.get(env_var, "auto")
+    if name not in MODE_ID:
+        raise GpuarError(f"unknown kernel mode {name!r} (auto, throughput, latency)")
+    return MODE_ID[name]
 
 
 def _check(code: int, what: str) -> None:
@@ -103,9 +121,10 @@ def _status_ptr(d_status):
     return d_status.data_ptr()
 
 
-def encode(d_in, d_slots=None, stream=None, d_status=None):
+def encode(d_in, d_slots=None, stream=None, d_status=None, mode=None):
     """Encode the bytes of `d_in` into 8704-byte packet slots (garCompress layout).  `d_status`: this launch's
-    own status word (a zeroed 1-element int32 CUDA tensor); None = the device's fallback word (status())."""
+    own status word (a zeroed 1-element int32 CUDA tensor); None = the device's fallback word (status()).
+    `mode`: "auto" | "throughput" | "latency" (gpuar_hip_encode_mode); None = $GPUAR_ENCODE_MODE, else auto."""
     import torch
     _require_cuda_u8(d_in, "d_in")
     n = d_in.numel()
@@ -115,7 +134,8 @@ def encode(d_in, d_slots=None, stream=None, d_status=None):
     _require_cuda_u8(d_slots, "d_slots")
     if d_slots.numel() < npk * SLOT:
         raise GpuarError("d_slots too small")
-    _check(load().gpuar_hip_encode(d_in.data_ptr(), n, d_slots.data_ptr(), _status_ptr(d_status), _stream_handle(stream)), "gpuar_hip_encode")
+    _check(load().gpuar_hip_encode_mode(d_in.data_ptr(), n, d_slots.data_ptr(), _status_ptr(d_status), _stream_handle(stream),
+                                        _mode_id(mode, "GPUAR_ENCODE_MODE")), "gpuar_hip_encode_mode")
     return d_slots
 
 

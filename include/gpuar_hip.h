@@ -100,6 +100,23 @@ size_t gpuar_hip_packet_count(size_t n_bytes);
  * (16-byte aligned, gpuar_hip_packet_count(n_bytes)*8704 bytes). */
 int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream);
 
+/* The same with the kernel named by the caller.  Both kernels write the same
+ * bytes; they differ in how a launch is cut into wavefronts:
+ *   GPUAR_MODE_THROUGHPUT  three working wavefronts per 64 packets (encode) / one per 64 packets (decode):
+ *                          the most bytes per second from a launch that fills the chip;
+ *   GPUAR_MODE_LATENCY     a finer cut (encode: six wavefronts per 64 packets) with a shorter symbol step:
+ *                          faster while the launch cannot fill the chip by itself;
+ *   GPUAR_MODE_AUTO        what gpuar_hip_encode / gpuar_hip_decode do: LATENCY up to 32768 packets
+ *                          (256 MiB of input), THROUGHPUT above -- right for a launch that has the
+ *                          chip to itself; a pipeline that keeps several launches in flight names
+ *                          THROUGHPUT.
+ * The choice is an argument, never an environment variable: this library reads no environment.
+ * Any other `mode` is GPUAR_ERR_ARGUMENT. */
+#define GPUAR_MODE_AUTO        0
+#define GPUAR_MODE_THROUGHPUT  1
+#define GPUAR_MODE_LATENCY     2
+int gpuar_hip_encode_mode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream, int mode);
+
 /* Decode n_packets slots at d_slots into d_out (n_packets*8192 bytes; the
  * last packet writes only its ulen bytes). */
 int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, uint32_t *d_status, void *stream);
@@ -135,8 +152,15 @@ int gpuar_hip_last_error(void);
 
 const char *gpuar_hip_error_string(int code);
 
-/* Build identification, e.g. "gpuar-hip 0.1 gfx950". */
+/* Build identification, e.g. "gpuar-hip 0.2 gfx950". */
 const char *gpuar_hip_version(void);
+
+/* The number of this header's ABI, GPUAR_HIP_ABI_VERSION at the time the library was built.  It changes whenever
+ * the signature of an existing entry point does (2: encode / decode / decode_stream take `d_status` in front of
+ * `stream`), so a caller built against another header can refuse to go on instead of passing a stream handle
+ * where a status word is expected:  if (gpuar_hip_abi_version() != GPUAR_HIP_ABI_VERSION) ...  */
+#define GPUAR_HIP_ABI_VERSION 2
+int gpuar_hip_abi_version(void);
 
 /* Synthetic streams of SURVEY.md section 8(d), generated on the device so
  * multi-GiB benchmark inputs never cross PCIe.  kind: 0 uniform, 1 zipf,

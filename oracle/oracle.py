@@ -12,6 +12,8 @@ this module.  Two libraries can sit behind it:
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import json
 import os
 import subprocess
 
@@ -22,7 +24,31 @@ PACKET_IN = 8192
 PACKET_SLOT = 8704
 HEADER_LEN = 20
 
+REF_LIB_PATH = os.path.join(HERE, "_ref", "libgpuar_ref.so")
+GOLDEN_JSON = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_vectors.json")
+
 _u8p = C.POINTER(C.c_uint8)
+
+
+class CheckerMismatch(RuntimeError):
+    """oracle/_ref/libgpuar_ref.so is not the file the golden vectors were made with."""
+
+
+def file_sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def pinned_checker_sha256():
+    """sha256 of oracle/_ref/libgpuar_ref.so as recorded by tests/golden/make_golden.py, or None if unrecorded."""
+    try:
+        with open(GOLDEN_JSON) as f:
+            return json.load(f).get("checker", {}).get("sha256")
+    except (OSError, ValueError):
+        return None
 
 
 def build(force: bool = False) -> None:
@@ -140,11 +166,23 @@ class PortOracle(_Codec):
 class ReferenceOracle(_Codec):
     kind = "reference"
 
-    def __init__(self):
+    def __init__(self, path: str = None, expect_sha256: str = "pinned"):
+        """`expect_sha256`: "pinned" = the hash tests/golden/ref_vectors.json records (the default: a checker that is not
+        the pinned file is REFUSED, not trusted); a hex string = that hash; None = no check (make_golden.py only, while
+        it produces the file's pin)."""
         build()
-        path = os.path.join(HERE, "_ref", "libgpuar_ref.so")
+        path = path or REF_LIB_PATH
         if not os.path.exists(path):
             raise FileNotFoundError(path)
+        want = pinned_checker_sha256() if expect_sha256 == "pinned" else expect_sha256
+        if expect_sha256 == "pinned" and want is None:
+            raise CheckerMismatch(f"{GOLDEN_JSON} records no checker sha256: run tests/golden/make_golden.py")
+        if want is not None:
+            have = file_sha256(path)
+            if have != want:
+                raise CheckerMismatch(f"{path}: sha256 {have} is not the pinned {want} -- this is not the library the golden "
+                                      "vectors were produced with (rebuilt from other sources, damaged or replaced); rebuild "
+                                      "it with oracle/build_ref.sh or re-pin with tests/golden/make_golden.py")
         lib = C.CDLL(path)
         super().__init__(lib, "ref_")
         lib.ref_decode_packet.restype = C.c_size_t
@@ -239,7 +277,7 @@ class ReferenceOracle(_Codec):
 
 
 def have_reference() -> bool:
-    return os.path.exists(os.path.join(HERE, "_ref", "libgpuar_ref.so"))
+    return os.path.exists(REF_LIB_PATH)
 
 
 def best():

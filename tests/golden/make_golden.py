@@ -96,7 +96,7 @@ def narrowest_greedy(n: int) -> np.ndarray:
 
 
 def main():
-    ref = O.ReferenceOracle()
+    ref = O.ReferenceOracle(expect_sha256=None)      # the file being pinned: nothing to check it against yet
     cases = []
 
     def add(name, data: np.ndarray, spec, keep_stream=False):
@@ -132,9 +132,15 @@ def main():
                                       "max_pending_bits": int(best_pending)}, keep_stream=True)
     add("uniform_s1_n65539_keep", synth.uniform(1, 65539), {"kind": "uniform", "seed": 1}, keep_stream=True)
 
+    # The checker binary itself is pinned: oracle/_ref/libgpuar_ref.so is git-ignored and cannot be rebuilt on the GPU
+    # box (no /root/reference there), so "bit-exact vs the reference" on the box would otherwise rest on whatever file
+    # was pushed.  ReferenceOracle() refuses a library whose sha256 is not the one recorded here, next to the
+    # vectors that very file produced.
     with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
         json.dump({"_provenance": "expected outputs produced by oracle/_ref (the reference's unmodified "
                                   "arCompress/arDecompress); regenerate with tests/golden/make_golden.py",
+                   "checker": {"file": "oracle/_ref/libgpuar_ref.so", "sha256": O.file_sha256(O.REF_LIB_PATH),
+                               "built_by": "oracle/build_ref.sh from /root/reference/src/gpuar_kernel.cu + oracle/ref_driver.cpp"},
                    "cases": cases}, f, indent=0)
     print(f"wrote {len(cases)} cases; midpoint hugger max pending = {best_pending}")
 

@@ -32,6 +32,44 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, n), n
 
 
+def declared_arity(header="gpuar_hip.h"):
+    """name -> number of parameters, read off the header's prototypes"""
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+    out = {}
+    for name, params in re.findall(r"\b(\w+)\s*\(([^;{]*)\)\s*;", text):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_bindings_pin_every_signature(lib):
+    """A binding with a different number of arguments than the header's prototype is how a stream handle ends up
+    where a status word is expected: the ctypes argtypes are checked against the header, and the
+    library's ABI number against the header's."""
+    from gpuar_amd import hip as H
+    for name, arity in declared_arity().items():
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None and len(fn.argtypes) == arity, (name, arity, fn.argtypes)
+    header = open(os.path.join(ROOT, "include", "gpuar_hip.h")).read()
+    abi = int(re.search(r"#define\s+GPUAR_HIP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.gpuar_hip_abi_version() == abi == H.ABI_VERSION
+    assert f"gpuar-hip 0.{abi} ".encode() in lib.gpuar_hip_version()
+
+
+def test_library_reads_no_environment(lib):
+    """The kernel choice is an argument of gpuar_hip_encode_mode; GPUAR_ENCODE_MODE is honoured by the Python shim only."""
+    import subprocess
+    from gpuar_amd import hip as H
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", H.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "libgpuar_hip.so imports getenv"
+    assert lib.gpuar_hip_encode_mode(None, 8192, None, None, None, 7) == -2      # unknown mode: GPUAR_ERR_ARGUMENT, before anything else
+    assert H._mode_id("latency", "GPUAR_ENCODE_MODE") == 2 and H._mode_id(None, "GPUAR_NO_SUCH_VARIABLE") == 0
+    with pytest.raises(H.GpuarError):
+        H._mode_id("fast", "GPUAR_ENCODE_MODE")
+
+
 def test_host_codec_symbols_are_exported_by_both_libraries(lib):
     import ctypes
     from gpuar_amd import host as HC
