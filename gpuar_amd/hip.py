@@ -22,7 +22,7 @@ EXPORTS = [
     "initConstantRange", "garCompressExecutor", "garDecompressExecutor",
     "gpuar_hip_packet_count", "gpuar_hip_encode", "gpuar_hip_encode_mode", "gpuar_hip_decode", "gpuar_hip_compact",
     "gpuar_hip_decode_stream", "gpuar_hip_status", "gpuar_hip_last_error", "gpuar_hip_error_string",
-    "gpuar_hip_version", "gpuar_hip_abi_version", "gpuar_hip_generate",
+    "gpuar_hip_version", "gpuar_hip_abi_version", "gpuar_hip_generate", "gpuar_hip_copy",
 ]
 ABI_VERSION = 2                      # GPUAR_HIP_ABI_VERSION of the header these bindings were written against
 MODE_ID = {"auto": 0, "throughput": 1, "latency": 2}     # GPUAR_MODE_*
@@ -74,6 +74,8 @@ def load() -> C.CDLL:
     lib.gpuar_hip_abi_version.argtypes = []
     lib.gpuar_hip_generate.restype = C.c_int
     lib.gpuar_hip_generate.argtypes = [C.c_int, C.c_uint64, C.c_uint64, sz, vp, vp]
+    lib.gpuar_hip_copy.restype = C.c_int
+    lib.gpuar_hip_copy.argtypes = [vp, vp, sz, vp]
     if lib.gpuar_hip_abi_version() != ABI_VERSION:
         raise GpuarError(f"{LIB_PATH} speaks ABI {lib.gpuar_hip_abi_version()}, these bindings {ABI_VERSION}: rebuild the library")
     _lib = lib
@@ -196,6 +198,17 @@ def generate(kind: str, seed: int, n: int, offset: int = 0, device="cuda", out=N
     _check(load().gpuar_hip_generate(KIND_ID[kind], seed & 0xFFFFFFFFFFFFFFFF, offset, n, out.data_ptr(),
                                      _stream_handle(stream)), "gpuar_hip_generate")
     return out
+
+
+def device_copy(d_src, d_dst, n_bytes: int = None, stream=None):
+    """Plain 16-byte-per-lane device copy (gpuar_hip_copy): the measured HBM roof of bench.py."""
+    _require_cuda_u8(d_src, "d_src")
+    _require_cuda_u8(d_dst, "d_dst")
+    n = d_src.numel() if n_bytes is None else n_bytes
+    if d_dst.numel() < n or d_src.numel() < n:
+        raise GpuarError("copy: buffer too small")
+    _check(load().gpuar_hip_copy(d_src.data_ptr(), d_dst.data_ptr(), n, _stream_handle(stream)), "gpuar_hip_copy")
+    return d_dst
 
 
 def gip_header(n_uncompressed: int, n_stream: int) -> bytes:

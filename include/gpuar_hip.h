@@ -167,6 +167,11 @@ int gpuar_hip_abi_version(void);
  * 2 text.  Fills d_out[0..n) with bytes [offset, offset+n) of the stream. */
 int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8_t *d_out, void *stream);
 
+/* Measurement support: a plain device-to-device copy of n_bytes (a multiple of 16; both pointers 16-byte aligned),
+ * 16 bytes per lane -- the practical HBM roof bench.py measures on the box and quotes next to the datasheet's
+ * 8 TB/s.  Moves 2 * n_bytes through HBM. */
+int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,22 @@ def test_self_launch_command_is_one_rank_per_gpu_on_loopback():
     assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "20"] and cmd[-5].endswith("bench.py")
+
+
+def test_every_roofline_object_carries_the_measured_roof_and_says_what_is_replayed():
+    """SURVEY.md section 8(d) "report both": the datasheet peak AND the copy peak measured in the same run; counter-derived
+    fields are marked as replayed from a stamped profile record, not passed off as measured live."""
+    t = {"source": "r09_traffic.json: pmc", "decode": {"hbm_bytes_per_launch": 2.0e10, "valu_busy": 0.6},
+         "encode": {"hbm_bytes_per_launch": 2.1e10}}
+    d = stub_line([], traffic=t)
+    d["roofline_compact"] = bench.hbm_roof(2 * 8658985568, 3.5)
+    copy_peak = {"GBps": 6100.0}
+    bench.annotate_roofs(d, copy_peak, t["source"])
+    for key in ("roofline", "roofline_encode", "roofline_decode", "roofline_compact"):
+        r = d[key]
+        assert r["peak"] == 8000.0 and r["peak_measured_copy"] == 6100.0
+        assert abs(r["frac_of_measured"] - r["achieved"] / 6100.0) < 1e-12 and r["frac_of_measured"] > r["frac"]
+        assert "measured_live" in r and "counters" in r
+    assert "replayed from profiles/r09_traffic.json" in d["roofline"]["counters"] and "valu_busy" in d["roofline"]["counters"]
+    assert d["roofline_compact"]["counters"].startswith("none quoted")
+    json.dumps(d)

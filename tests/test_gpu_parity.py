@@ -120,6 +120,18 @@ def test_device_generators_match_numpy(H):
             assert np.array_equal(got, synth.generate(kind, 9, n, offset=off)), (kind, off, n)
 
 
+def test_device_copy_copies(H):
+    """gpuar_hip_copy (bench.py's measured HBM roof) moves exactly the bytes it is given, for sizes around its
+    four-quads-per-thread loop and its grid cap."""
+    for n in (16, 16 * 255, 16 * 1024 * 4 + 16, (8192 * 1024 * 16) + 48, 64 << 20):
+        src = H.generate("uniform", 3, n + 32)
+        dst = torch.zeros(n + 32, dtype=torch.uint8, device="cuda")
+        H.device_copy(src, dst, n)
+        assert torch.equal(dst[:n], src[:n]) and int(dst[n:].sum()) == 0, n
+    with pytest.raises(H.GpuarError):
+        H.device_copy(src, dst, 24)                      # not a multiple of 16
+
+
 @pytest.mark.parametrize("kind", ["uniform", "zipf", "text", "zeros"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 8191, 8192, 8193, 64 * 8192, 64 * 8192 + 1, 200 * 8192 + 4097])
 def test_slots_equal_oracle(H, oracle, kind, n, encode_mode):
