@@ -66,10 +66,10 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // <-> packet 64*group + l in all three); which wavefront plays which role is
 // decided per SIMD at run time (see encode_kernel):
 //   TOP MODELER: reads the input bytes from memory (whole 128-byte lines), walks
-//           depths 1..6 of the 64 adaptive models (LDS), emits its part of
+//           depths 1..4 of the 64 adaptive models (LDS), emits its part of
 //           cumLo | cumHi << 16 per symbol and hands the bytes on;
-//   LOW MODELER: one phase behind: depth 0 (a register), depth 7 (LDS) and the
-//           x == 255 term, added onto the top modeler's part in place (why 6 + 1:
+//   LOW MODELER: one phase behind: depth 0 (a register), depths 5..7 (LDS) and the
+//           x == 255 term, added onto the top modeler's part in place (why 4 + 3:
 //           lane_codec.h at TopModeler);
 //   CODER: two phases behind: owns the interval state and the bit sink, turns the
 //           sums into the packet bitstream;
@@ -93,7 +93,14 @@ constexpr uint32_t kPhase = 8;
 // (tools/kind_timing.py): all equal 6.14 ms; coder first 6.25; top modeler first 5.90; top > coder > low 5.70;
 // top > low > coder 5.87; with the 4-level share of the tree moved to the low modeler the same numbers with the
 // roles swapped -- whoever walks four LDS levels has to go first, the three-level modeler last.
-constexpr int kPrioTop = 3, kPrioCoder = 1, kPrioLow = 0;
+// Round 4 (the coder in carry form, ten vector instructions shorter): top > low > coder.  With the old order the lighter coder
+// bought nothing (5.14 ms for 6 + 1 and 5 + 2 depths alike); with the coder last 4.96-4.99 ms for 5 + 2, 4 + 3 and 3 + 4.
+#ifndef GPUAR_PRIO_TOP
+#define GPUAR_PRIO_TOP 3
+#define GPUAR_PRIO_CODER 0
+#define GPUAR_PRIO_LOW 2
+#endif
+constexpr int kPrioTop = GPUAR_PRIO_TOP, kPrioCoder = GPUAR_PRIO_CODER, kPrioLow = GPUAR_PRIO_LOW;
 
 // The three roles work one phase apart -- the top modeler on the symbols of phase p, the low modeler on those of
 // p - 1, the coder on those of p - 2 -- and hand a phase on IN PLACE: the top modeler writes its part of
@@ -335,7 +342,11 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         __builtin_amdgcn_s_setprio(kPrioCoder);
         // slot address = (wave-uniform base of this block's first slot) + lane * 8704
         uint8_t *block_slots = dst + group * (kLanes * kSlot);
+#ifdef GPUAR_CODER_OWED_BITS            // (A/B builds only: the coder of rounds 1-3)
         CoderLane coder;
+#else
+        CarryCoderLane coder;                // the lower bound as a 64-bit window, carries instead of owed bits (lane_codec.h)
+#endif
         coder.open(block_slots, lane * kSlot);
         Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
 #pragma unroll
@@ -530,7 +541,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
     } else if (wave == 5u) {
         small_follow<PartialModeler<7, 5, 2, 0, false>>(lds, lane, len, len_min, n_phases, 2u);
     } else if (wave == 0u) {
-        small_follow<LowModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
+        small_follow<DeepestModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
     } else if (wave == 2u) {
         IntervalLane interval;
         interval.open();

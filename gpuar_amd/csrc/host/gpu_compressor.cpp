@@ -13,8 +13,12 @@
 //
 // Each GPU runs kLanesPerDevice lanes at once, each a host thread with its own non-blocking HIP stream,
 // device buffers, pinned pieces and status word, so the copies and kernels of one chunk overlap the
-// draining of another; chunks are dealt to the GPUs round-robin (chunk c -> device c mod G), which is the
-// contiguous-packet-range sharding of SURVEY.md section 8(e) at chunk grain.  What bounds the wall time
+// draining of another.  The file is cut into contiguous packet ranges (chunks) in file order, sized so that every lane of
+// every device gets one (ensureBuffers: at most ceil(packets / (G * lanes)) packets each, whole wavefronts), and chunk c
+// goes to device c mod G: the packet-range sharding of SURVEY.md section 8(e) at CHUNK grain -- every device codes the same
+// number of chunks to within one, hence the same bytes to within one chunk -- dealt in file order because the one writer
+// consumes in file order (one contiguous range per device would have devices 1..G-1 finish their first chunks and then hold
+// them, pinned, until the writer is through all of device 0's range).  What bounds the wall time
 // on a page-cached file is the ONE thing that cannot be spread: buffered writes to a single file are
 // serialised by the file system (tools/io_probe.cpp: ~9-11 GB/s into a new file whatever the number of
 // threads, against 57 GB/s per direction over PCIe and 76+ GB/s of pread), so the pipeline is built to keep
@@ -646,6 +650,8 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
         std::vector<std::vector<uint16_t>> chunk_clens(writeIndex ? n_chunks : 0);     // for the optional index trailer
         std::vector<std::atomic<size_t>> next_of_device(G);
         for (auto &n : next_of_device) n = 0;
+        std::vector<std::atomic<uint64_t>> device_bytes(G), device_chunks(G);      // what each device coded (GPUAR_TRACE)
+        for (size_t g = 0; g < G; ++g) device_bytes[g] = 0, device_chunks[g] = 0;
         std::mutex progress_lock;
         {
             Writer writer(out_fd, true, FileHeader::HEADER_LENGTH, "Write compressed data to output file failed");
@@ -687,6 +693,8 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                                 chunk_clens[c].resize(n_packets);
                                 for (size_t p = 0; p < n_packets; ++p) chunk_clens[c][p] = static_cast<uint16_t>(b.h_offsets[p + 1] - b.h_offsets[p]);
                             }
+                            device_bytes[g] += n_plain;
+                            device_chunks[g] += 1;
                             b.drain(writer, c, b.d_stream, n_stream, 0, n_plain);     // the ordered writer knows where chunk c goes
                         }
                     },
@@ -701,6 +709,9 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                 std::rethrow_exception(lane_failure);
             }
             trace("compress: lanes done");
+            for (size_t g = 0; g < G; ++g)
+                trace(("compress: device " + std::to_string(g) + " coded " + std::to_string(device_bytes[g].load()) + " bytes in " +
+                       std::to_string(device_chunks[g].load()) + " chunks of at most " + std::to_string(chunkPackets * kPacket) + " bytes").c_str());
             info.compressedFileSize = static_cast<size_t>(writer.finish(n_chunks));
         }
         uint64_t file_end = info.compressedFileSize;
@@ -955,6 +966,8 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
         OrderedOffsets place;
         std::vector<std::atomic<size_t>> next_of_device(G);
         for (auto &n : next_of_device) n = 0;
+        std::vector<std::atomic<uint64_t>> device_bytes(G), device_chunks(G);      // what each device decoded (GPUAR_TRACE)
+        for (size_t g = 0; g < G; ++g) device_bytes[g] = 0, device_chunks[g] = 0;
         std::mutex progress_lock;
         {
             Writer writer(out_fd, false, 0, "Write uncompressed data to output file failed");
@@ -1010,6 +1023,8 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                             if (off != n_stream) throw std::runtime_error("Invalid file length");
                             b.h_offsets[chunk.n_packets] = off;
                             const uint64_t out_at = place.take(c, produced);
+                            device_bytes[g] += produced;
+                            device_chunks[g] += 1;
                             const uint32_t flags = b.decodeChunk(chunk.n_packets);
                             if (flags & GPUAR_STATUS_BAD_PACKET)
                                 throw std::runtime_error("Incorrect file format (malformed packet between file offsets " + std::to_string(chunk.begin) +
@@ -1042,6 +1057,9 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                 std::rethrow_exception(lane_failure);
             }
             trace("decompress: lanes done");
+            for (size_t g = 0; g < G; ++g)
+                trace(("decompress: device " + std::to_string(g) + " decoded " + std::to_string(device_bytes[g].load()) + " bytes in " +
+                       std::to_string(device_chunks[g].load()) + " chunks").c_str());
             (void)writer.finish(0);
         }
         info.uncompressedFileSize = info.processedUncompressedSize = static_cast<size_t>(place.sum());     // what the packets held

@@ -353,14 +353,22 @@ struct PartialModeler {
     }
 };
 
-// How the tree is dealt to the two modelers (measured on the GPU, uniform 2 GiB): the wavefront
-// that issues first (the "top" modeler, highest priority) spends its time waiting for LDS round trips and has
-// issue slots to spare, so it takes six of the seven LDS-resident depths; the other one keeps depth 0 in a
-// register, depth 7 and the x == 255 term.  4 + 3 depths: 5.71 ms; 5 + 2: 5.43; 6 + 1 (this): 5.36; 7 + 0: 5.75.
+// How the tree is dealt to the two modelers (measured on the GPU, uniform 2 GiB).  Rounds 1-3, with the
+// 43-instruction coder: 4 + 3 depths 5.71 ms, 5 + 2 5.43, 6 + 1 5.36, 7 + 0 5.75 -- the SIMDs issued a vector instruction in 98 %
+// of their slots and the top modeler, which went first, carried what it could.  Round 4: the coder in carry form is ten vector
+// instructions shorter and now goes LAST (issue priorities top > low > coder, gpuar_kernels.hip); 6 + 1 stays at 5.14 ms whatever
+// the coder weighs (the top modeler's own stream -- 33 vector instructions and 14 LDS operations per symbol, each LDS operation
+// holding its wavefront's issue for 12-20 cycles -- is as long as the phase), 5 + 2, 4 + 3 and 3 + 4 all take 4.96-4.99.
+#ifndef GPUAR_TOP_DEPTHS
+#define GPUAR_TOP_DEPTHS 4          // LDS-resident depths the top modeler walks (1 .. GPUAR_TOP_DEPTHS); the low modeler takes the rest
+#endif
 template <uint32_t kRowShift>
-using TopModeler = PartialModeler<kRowShift, 1, 6, 0, false>;       // depths 1..6
+using TopModeler = PartialModeler<kRowShift, 1, GPUAR_TOP_DEPTHS, 0, false>;                              // depths 1..
 template <uint32_t kRowShift>
-using LowModeler = PartialModeler<kRowShift, 7, 1, 1, true>;        // depth 0 (register), depth 7 and the x == 255 term
+using LowModeler = PartialModeler<kRowShift, 1 + GPUAR_TOP_DEPTHS, 7 - GPUAR_TOP_DEPTHS, 1, true>;        // depth 0 (register), the deepest ones and the x == 255 term
+// the last role of the latency kernel's four-way tree: depth 0 (register), depth 7 and the x == 255 term, whatever the split above
+template <uint32_t kRowShift>
+using DeepestModeler = PartialModeler<kRowShift, 7, 1, 1, true>;
 
 // Range coder of one packet, fed with cumLo | cumHi << 16 per symbol.
 // State: the interval as its lower bound and its WIDTH (lo, range = hi - lo + 1): both renormalise
@@ -493,6 +501,230 @@ struct CoderLane {
         const uint32_t pos = at - body_off;                   // bytes stored (or attempted) after the header
         const uint32_t tail_bytes = (n + 7u) >> 3;
         const uint32_t word = n ? (acc << (32u - n)) : 0u;
+        uint32_t clen = pos + tail_bytes + kHdr;
+        overflowed = clen > kSlot;
+        if (overflowed) {
+            clen = kSlot;
+        } else {
+            for (uint32_t k = 0; k < tail_bytes; ++k) body[pos + k] = static_cast<uint8_t>(word >> (24u - 8u * k));
+        }
+        const uint32_t hdr = clen | (ulen << 16);             // u16 LE clen, u16 LE ulen (:525-528)
+        memcpy(body - kHdr, &hdr, 4);
+        return clen;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// The same coder in CARRY form (round 4; the throughput kernel's coder role).
+//
+// writeEncodedBits (:321-367) keeps lower and upper as 16-bit registers and never lets a carry out of them: while the
+// interval straddles the midpoint (lower = 01.., upper = 10..) it takes 0x4000 off both, doubles them and OWES one bit
+// ("underflow"), to be emitted -- as the complement of the next agreed bit -- once the bounds agree again.  CoderLane
+// above does exactly that in closed form (agreed bits with `pending` complements spliced in behind their first one), and
+// that splice is most of its 43 instructions.  Here the lower bound is kept as what it really is -- the low end of ONE
+// long binary fraction --: a 64-bit window w whose bits [0, 16) are the live lower bound, bits [16, 16 + held) the `held`
+// newest output bits still in the register, and the bit above them a carry out of them.  A symbol then costs
+//     w += dn  (a carry, if any, runs through the held bits by itself),   w <<= n,   held += n
+// -- n = e + u, ONE count of leading zeros (renorm_count) -- and the 32 oldest held bits leave as a dword when held >= 32.
+//
+// Why the bytes are the same.  Taking 0x4000 off a 16-bit register and doubling it (mod 2^16) is doubling it and
+// flipping bit 15, so between symbols the reference's lower = w[15:0] ^ K with K = 0x8000 while bits are owed, 0
+// otherwise; the widths agree (range = upper - lower + 1 is the same number in both forms), hence dn, up, and -- K
+// cancels in a ^ h -- renorm_count.  The first underflow shifts a true 0 out of w, every further one a true 1 (bit 15 of
+// w is the flipped 0 of lower): p owed bits stand in the stream as 0 1..1 (p - 1 ones) plus the set bit 15.  When the
+// bounds next agree on b, the reference emits b and p complements: b = 0 is 0 1..1 1 -- what w shifts out anyway; b = 1
+// means lower crossed 0x8000, i.e. w[15:0] crossed 2^16: the carry turns 0 1..1 into 1 0..0 and a 0 follows.  The end of
+// the packet (writeRemaining :379-388: bit 14 of lower, then pending + 1 complements) is  w += 0x4000  and two more bits.
+// n <= 16 (range' = width << n <= 2^16), held < 32 between symbols, so 16 + held + n <= 64: the window never overflows.
+//
+// A run of owed bits does not care where a dword ends: its leading 0 may have left the window while its ones are still
+// in it (6 % of the dwords of a uniform stream), so a dword that leaves is not final yet.  It is kept back one store
+// (`cache`) and takes the carry found above the NEXT dword when that one leaves -- cache + carry, one add in front of
+// the store; a dword can be carried into once at most (after the carry everything below it is zero, and the interval is
+// far too narrow to reach the next multiple).  A leaving dword of 32 ones cannot be kept back that way -- a carry would
+// run through it -- so it is only counted (`nff`) and written, as ones or as zeros, when the next decided dword leaves:
+// the classic carry-counting range coder at dword grain.  That is the rare path (one leaving dword in 2^32 on random
+// data; the packet that owes 2396 bits, tests/golden/adversarial_midpoint, counts 74 of them).  The very first `cache`
+// is a placeholder that lands on the packet's header dword, which finish() overwrites.
+// Pinned against the oracle on the CPU like every other lane program (tests/test_lane_emulation.py).
+// ---------------------------------------------------------------------------
+struct CarryCoderLane {
+    uint32_t wl, wh;     // the window w = wh:wl
+    uint32_t range;      // hi - lo + 1  (2^14 < range <= 2^16 between symbols)
+    uint32_t held;       // output bits in the window (< 32 between symbols)
+    uint32_t cache;      // the dword that left the window last: written (plus a carry) when the next one leaves
+    uint32_t nff;        // dwords of 32 ones that left behind `cache` and wait with it
+    uint32_t at;         // offset from `base` where `cache` will be written
+    uint32_t last;       // offset of the last dword of the slot: stores beyond it land there
+    uint32_t kff;        // low half 0xFFFF, high half scratch of the renormalisation count
+    uint8_t *base;       // same pointer in every lane of a wavefront (scalar register on the GPU)
+    uint32_t body_off;   // this lane's byte offset of slot + 4
+
+    GPUAR_LANE void open(uint8_t *uniform_base, uint32_t slot_offset) {
+        wl = 0;           // lo = 0, hi = 0xFFFF  (:492-494)
+        wh = 0;
+        range = 0x10000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        held = 16u;       // the GPU's step keeps this count 16 too high (its shifts then take it as it is); finish() undoes that
+#else
+        held = 0;
+#endif
+        cache = 0;        // the placeholder: its "store" lands on the header dword
+        nff = 0;
+        kff = 0xFFFFu;
+        base = uniform_base;
+        body_off = slot_offset + kHdr;
+        at = slot_offset;
+        last = slot_offset + kSlot - 4u;
+    }
+
+    GPUAR_LANE void store_clamped(uint32_t word) {           // a packet that outgrows its slot keeps overwriting the slot's last dword
+        store32(base + (at < last ? at : last), bswap32(word));
+        at += 4u;
+    }
+
+    // the 32 oldest held bits leave the window (held >= 32); returns them and, through `over`, the carry found above them
+    GPUAR_LANE uint32_t take_top(uint32_t &over) {
+        const uint32_t s = held - 16u;                               // 16 <= s < 32: the dword is bits [s, s + 32) of w
+        const uint32_t word = GPUAR_ALIGNBIT(wh, wl, s);
+        over = wh >> s;
+        wl &= GPUAR_BFM(s, 0u);
+        wh = 0;
+        held -= 32u;
+        return word;
+    }
+
+    // a dword has left the window with `over` above it: the complete rule (the GPU's common path is its first line)
+    GPUAR_LANE void leave(uint32_t word, uint32_t over) {
+        if (word != 0xFFFFFFFFu || over) {
+            store_clamped(cache + over);
+            for (; nff; --nff) store_clamped(over ? 0u : 0xFFFFFFFFu);
+            cache = word;
+        } else {
+            ++nff;
+        }
+    }
+
+    GPUAR_LANE void step(uint32_t cums, Recip rc) {
+        const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
+        const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
+        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+#if defined(__HIP_DEVICE_COMPILE__)
+        // w += dn; n = renorm_count(w[15:0], wd) -- one statement: the xor lands in HALF a register (SDWA) and may be read
+        // by the second instruction behind it at the earliest, so the order is fixed here
+        uint32_t h, t2, c, t, n;
+        asm("v_add_co_u32 %[wl], vcc, %[wl], %[dn]\n\t"
+            "v_addc_co_u32 %[wh], vcc, 0, %[wh], vcc\n\t"
+            "v_add3_u32 %[h], %[wl], %[wd], -1\n\t"                   /* new hi, low 16 bits */
+            "v_lshl_add_u32 %[t2], %[wd], 16, %[km]\n\t"              /* (2 * width - 1) << 15 */
+            "v_xor_b32_sdwa %[kff], %[wl], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+            "v_ffbh_u32 %[c], %[t2]\n\t"
+            "v_lshlrev_b32 %[t], %[c], %[kff]\n\t"
+            "v_lshrrev_b32 %[t], 31, %[t]\n\t"
+            "v_add3_u32 %[n], %[c], %[t], -1"
+            : [wl] "+v"(wl), [wh] "+v"(wh), [kff] "+v"(kff), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
+            : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u)
+            : "vcc");
+        range = wd << n;
+        {
+            const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
+            wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        }
+        held += n;
+        // The store region, predicated by hand, NO branch around it (some lane has a dword leaving on almost every symbol):
+        // the common line of leave() -- cache + carry goes to memory, the leaving dword becomes the cache.  Lanes for which
+        // that is not the whole story (a leaving dword of 32 ones, or such dwords waiting) are named in `rare` and put
+        // right behind the region, from what the region left: `sent` (what was stored), `word`, `over`.
+        // (every shift below takes `held` itself as its count: the hardware looks at the low five bits only, and
+        // held - 16 = held + 16 (mod 32) -- so the device keeps `held` 16 too high, see open())
+        const unsigned long long full = __builtin_amdgcn_ballot_w64(held >= 48u);
+        unsigned long long saved;
+        uint32_t word, over, sent, t_mask, t_addr, t_swapped;
+        asm volatile(
+            "s_and_saveexec_b64 %[sx], %[m]\n\t"
+            "v_alignbit_b32 %[word], %[wh], %[wl], %[held]\n\t"
+            "v_lshrrev_b32 %[over], %[held], %[wh]\n\t"
+            "v_bfm_b32 %[tm], %[held], 0\n\t"
+            "v_add_u32 %[sent], %[cache], %[over]\n\t"
+            "v_min_u32 %[ta], %[at], %[last]\n\t"
+            "v_perm_b32 %[tw], 0, %[sent], %[sel]\n\t"
+            "global_store_dword %[ta], %[tw], %[base]\n\t"
+            "v_and_b32 %[wl], %[wl], %[tm]\n\t"
+            "v_mov_b32 %[wh], 0\n\t"
+            "v_mov_b32 %[cache], %[word]\n\t"
+            "v_add_u32 %[at], 4, %[at]\n\t"
+            "v_add_u32 %[held], -32, %[held]\n\t"
+            "s_or_b64 exec, exec, %[sx]"
+            : [wl] "+v"(wl), [wh] "+v"(wh), [at] "+v"(at), [held] "+v"(held), [cache] "+v"(cache), [word] "=&v"(word),
+              [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped), [sx] "=&s"(saved)
+            : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base)
+            : "memory");
+#ifndef GPUAR_CARRY_NO_RARE        // (timing experiments only: without the rare path the kernel is WRONG for dwords of 32 ones)
+        // one compare finds both kinds: `key` is 0xFFFFFFFF (word >= key: 32 ones) or, while dwords wait, 0 (always)
+        const unsigned long long rare = __builtin_amdgcn_ballot_w64(word >= key) & full;
+        if (__builtin_expect(rare != 0ull, 0)) {              // wave-uniform (a lane mask from a ballot)
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if ((rare >> lane) & 1ull) {
+                if (word == 0xFFFFFFFFu && over == 0u) {      // not decided yet: it waits, and so does the cache again
+                    at -= 4u;
+                    cache = sent;
+                    ++nff;
+                } else {                                      // decided: the waiting dwords go out behind what was just stored
+                    for (; nff; --nff) store_clamped(over ? 0u : 0xFFFFFFFFu);
+                }
+            }
+            key = nff ? 0u : 0xFFFFFFFFu;
+        }
+#endif
+#ifdef GPUAR_CARRY_JOIN_ASM
+        else {
+            // (no instruction: what the rare path may change is "redefined" on this side of the join as well, in place, so that the
+            // register allocator has no reason to copy it where the two sides meet)
+            asm volatile("" : "+v"(key), "+v"(nff), "+v"(at), "+v"(cache));
+        }
+#endif
+#else
+        const uint64_t sum = ((static_cast<uint64_t>(wh) << 32) | wl) + dn;
+        const uint32_t n = renorm_count(static_cast<uint32_t>(sum) & 0xFFFFu, wd);
+        const uint64_t w = sum << n;                          // 16 + held + n <= 64 (+ the carry bit above the held ones)
+        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        range = wd << n;
+        held += n;
+        if (held >= 32u) {
+            uint32_t over;
+            const uint32_t word = take_top(over);
+            leave(word, over);
+        }
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t key = 0xFFFFFFFFu;       // what a leaving dword is compared with to find the rare cases: 0 while nff != 0
+#endif
+
+    // writeRemaining (:379-388) + writeClose (:430-439) in carry form (derivation in the header comment): + 0x4000, two
+    // more bits, zero padding to a byte.  Once per packet: plain code.
+    GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        held -= 16u;
+#endif
+        const uint64_t w = ((((static_cast<uint64_t>(wh) << 32) | wl) + 0x4000u) << 2);
+        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        held += 2u;                                           // < 34
+        if (held >= 32u) {
+            uint32_t over;
+            const uint32_t word = take_top(over);
+            leave(word, over);
+        }
+        // what is left: `held` (< 32) bits at [16, 16 + held), perhaps a carry above them: everything is decided now
+        const uint32_t top = GPUAR_ALIGNBIT(wh, wl, 16u);     // bits [16, 48) of w
+        const uint32_t bits = held ? (top & GPUAR_BFM(held, 0u)) : 0u;
+        const uint32_t over = held ? (top >> held) : top;     // (held < 32: the carry, if any, is inside `top`)
+        store_clamped(cache + over);
+        for (; nff; --nff) store_clamped(over ? 0u : 0xFFFFFFFFu);
+        uint8_t *body = base + body_off;
+        const uint32_t pos = at - body_off;                   // bytes stored (or attempted) after the header
+        const uint32_t tail_bytes = (held + 7u) >> 3;
+        const uint32_t word = held ? (bits << (32u - held)) : 0u;
         uint32_t clen = pos + tail_bytes + kHdr;
         overflowed = clen > kSlot;
         if (overflowed) {

@@ -14,11 +14,10 @@ using namespace gpuar;
 static const RecipTable kRecip = RecipTable();
 static const DecodeConstTable kDecode = DecodeConstTable();
 
-extern "C" {
-
-// What the three encoder wavefronts do (TopModeler + LowModeler + CoderLane), packet by packet.
+// What the three encoder wavefronts do (TopModeler + LowModeler + a coder), packet by packet.
 // slots: ceil(n/8192) * 8704 bytes.  Returns the OR of per-packet overflow flags.
-int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+template <typename Coder>
+static int encode_slots_with(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 {
     int any_overflow = 0;
     const size_t np = (n_bytes + kPacket - 1) / kPacket;
@@ -30,7 +29,7 @@ int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         LowModeler<1> low;
         top.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
         low.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
-        CoderLane coder;
+        Coder coder;
         coder.open(slots, static_cast<uint32_t>(p * kSlot));
         for (uint32_t i = 0; i < len; ++i) {
             const uint32_t next = i + 1 < len ? in[off + i + 1] : 0u;
@@ -43,6 +42,14 @@ int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     }
     return any_overflow;
 }
+
+extern "C" {
+
+// encode_kernel's coder: the carry form (CarryCoderLane)
+int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots) { return encode_slots_with<CarryCoderLane>(in, n_bytes, slots); }
+// the reference's own shape -- 16-bit bounds, bits owed while they straddle the midpoint -- in closed form (CoderLane;
+// cut in two it is the latency kernel's coder, emu_encode_slots_split)
+int emu_encode_slots_e3(const uint8_t *in, size_t n_bytes, uint8_t *slots) { return encode_slots_with<CoderLane>(in, n_bytes, slots); }
 
 // The same the way the kernel's three roles run it: in phases of 8 symbols, the top modeler's parts first, the
 // low modeler one phase later adding its own ONTO them -- without a look at the next phase (prime() at the start
@@ -60,7 +67,7 @@ int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         LowModeler<1> low;
         top.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
         low.open(reinterpret_cast<uint8_t *>(table.data()), 0, 0);
-        CoderLane coder;
+        CarryCoderLane coder;
         coder.open(slots, static_cast<uint32_t>(p * kSlot));
         for (uint32_t base = 0; base < len; base += kPhase) {
             const uint32_t count = len - base < kPhase ? len - base : kPhase;
@@ -101,7 +108,7 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
         PartialModeler<1, 1, 3, 0, false> upper;
         PartialModeler<1, 4, 3, 0, false> middle;
-        LowModeler<1> low;
+        DeepestModeler<1> low;
         uint8_t *t = reinterpret_cast<uint8_t *>(table.data());
         upper.open(t, 0, in[off]);
         middle.open(t, 0, 0);

@@ -35,6 +35,8 @@ def emu():
     lib = C.CDLL(so)
     lib.emu_encode_slots.restype = C.c_int
     lib.emu_encode_slots.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_e3.restype = C.c_int
+    lib.emu_encode_slots_e3.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_encode_slots_phased.restype = C.c_int
     lib.emu_encode_slots_phased.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_encode_slots_split.restype = C.c_int
@@ -111,6 +113,39 @@ def test_latency_mode_roles_give_the_same_slots(emu, c):
     got = np.zeros_like(want)
     assert emu.emu_encode_slots_split(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_carry_form_coder_equals_the_owed_bits_form(emu, c):
+    """CarryCoderLane (encode_kernel's coder since round 4: the lower bound as a 64-bit window of one long binary fraction,
+    carries running through the bits not yet stored and -- rarely -- back into memory) against CoderLane, which mirrors
+    the reference's 16-bit bounds and owed underflow bits (writeEncodedBits :321-367): the same slots byte for byte, the
+    packet that owes 2396 bits (a carry through 75 stored dwords) included."""
+    data = np.ascontiguousarray(case_input(c))
+    want = np.zeros(((data.size + 8191) // 8192) * 8704, dtype=np.uint8)
+    ov = emu.emu_encode_slots_e3(data.ctypes.data_as(u8p), data.size, want.ctypes.data_as(u8p))
+    got, npk, ov2 = emu_encode(emu, data)
+    assert ov == ov2 == 0 and np.array_equal(got, want)
+
+
+def test_carry_form_coder_on_streams_that_keep_carrying(emu, port_oracle):
+    """Inputs built to make carries travel: two symbols whose boundary sits at the interval's midpoint (long runs of
+    owed bits resolved both ways), and few-symbol alphabets at every skew."""
+    rng = np.random.default_rng(29)
+    for trial in range(40):
+        n = int(rng.integers(2000, 8193))
+        if trial % 4 == 0:
+            data = np.where(rng.random(n) < 0.5, 0x7F, 0x80).astype(np.uint8)
+        elif trial % 4 == 1:
+            data = rng.choice(np.array([0x7F, 0x80, 0x00, 0xFF], dtype=np.uint8), n, p=[0.45, 0.45, 0.05, 0.05])
+        elif trial % 4 == 2:
+            k = int(rng.integers(2, 6))
+            data = rng.choice(rng.integers(0, 256, k).astype(np.uint8), n)
+        else:
+            data = np.repeat(rng.integers(0, 256, n // 64 + 1).astype(np.uint8), 64)[:n]
+        slots, npk, ov = emu_encode(emu, np.ascontiguousarray(data))
+        stream, _ = slots_to_stream(slots, npk)
+        assert ov == 0 and np.array_equal(stream, port_oracle.encode_stream(data)), trial
 
 
 def test_renormalisation_count_in_one_clz_equals_the_loop(emu):
