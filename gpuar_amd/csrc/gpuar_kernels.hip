@@ -403,8 +403,8 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 //     MID1     depths 3-4, added onto the sums in place                               13 + 6
 //     MID2     depths 5-6, added in place                                             13 + 6
 //     LOW      depth 0 (register), depth 7, the x == 255 term, added in place         15 + 4
-//     INTERVAL interval narrowing + renormalisation counts -> one word per symbol     ~24 + 2   (lane_codec.h IntervalLane)
-//     SINK     pending bits, accumulator, stores                                      ~31 + 1   (SinkLane)
+//     INTERVAL interval narrowing + renormalisation count -> one word per symbol      ~18 + 2   (lane_codec.h CarryIntervalLane)
+//     SINK     the window of held bits, carries, stores                               ~19 + 1   (CarrySinkLane)
 // Same integers as the throughput kernel (lane_codec.h is shared; tests/test_lane_emulation.py pins the cut coder
 // and a three-way tree against the oracle on the CPU), a different cut.  Rings: five slots of sums, four of input
 // bytes, two of interval words: 48 KiB of LDS per workgroup.  Every role meets n_phases + 5 barriers.
@@ -421,8 +421,7 @@ struct EncodeSmallLds {
     uint8_t tree[kTreeRows * kLanes * 2];     // 32 KiB
     uint32_t sums[kSumSlots][kSmallPhase][kLanes];    // [slot][symbol][lane], cumLo | cumHi << 16 in the making
     uint32_t bytes[kByteBufs][kSmallPhase / 4][kLanes];    // the input bytes of a phase
-    uint32_t words[2][kSmallPhase][kLanes];   // IntervalLane -> SinkLane
-    uint32_t final_lo[kLanes];                // ... and, once per packet, the lower bound behind its last symbol
+    uint32_t words[2][kSmallPhase][kLanes];   // CarryIntervalLane -> CarrySinkLane: dn | n << 16 per symbol
 };
 
 // the input bytes of one phase at in + at (a multiple of the phase length), zero beyond `len`
@@ -543,7 +542,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
     } else if (wave == 0u) {
         small_follow<DeepestModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
     } else if (wave == 2u) {
-        IntervalLane interval;
+        CarryIntervalLane interval;
         interval.open();
         for (uint32_t b = 0; b < kSmallLag - 1u; ++b) lds_barrier();
         for (uint32_t k = 0; k < n_phases; ++k) {
@@ -566,10 +565,9 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             }
             lds_barrier();
         }
-        lds.final_lo[lane] = interval.lo;                     // (read behind two more barriers)
         lds_barrier();
     } else {
-        SinkLane sink;
+        CarrySinkLane sink;
         sink.open(dst + group * (kLanes * kSlot), lane * kSlot);
         for (uint32_t b = 0; b < kSmallLag; ++b) lds_barrier();
         for (uint32_t k = 0; k < n_phases; ++k) {
@@ -590,7 +588,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         }
         if (live) {
             bool overflowed;
-            sink.finish(len, overflowed, lds.final_lo[lane]);
+            sink.finish(len, overflowed);
             if (overflowed) atomicOr(status, GPUAR_STATUS_SLOT_OVERFLOW);
         }
     }

@@ -31,7 +31,7 @@ size_t encode_one(const uint8_t *in, uint32_t len, uint8_t *slot) {
     gpuar::LowModeler<1> low;
     top.open(col, 0, in[0]);
     low.open(col, 0, in[0]);
-    gpuar::CoderLane coder;
+    gpuar::CarryCoderLane coder;     // (the carry form: the same bytes in fewer operations, lane_codec.h)
     coder.open(slot, 0);
     for (uint32_t i = 0; i < len; ++i) {
         const uint32_t x = in[i], next = i + 1 < len ? in[i + 1] : 0u;

@@ -605,27 +605,10 @@ struct CarryCoderLane {
         }
     }
 
-    GPUAR_LANE void step(uint32_t cums, Recip rc) {
-        const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
-        const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
-        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+    // w <<= n, held += n, and the dword on top of the held bits leaves once there are 32 (the GPU's version of
+    // take_top() + leave(); shared by the throughput kernel's coder and the latency kernel's sink)
 #if defined(__HIP_DEVICE_COMPILE__)
-        // w += dn; n = renorm_count(w[15:0], wd) -- one statement: the xor lands in HALF a register (SDWA) and may be read
-        // by the second instruction behind it at the earliest (DESIGN.md 4.1 item 7), so the order is fixed here
-        uint32_t h, t2, c, t, n;
-        asm("v_add_co_u32 %[wl], vcc, %[wl], %[dn]\n\t"
-            "v_addc_co_u32 %[wh], vcc, 0, %[wh], vcc\n\t"
-            "v_add3_u32 %[h], %[wl], %[wd], -1\n\t"                   /* new hi, low 16 bits */
-            "v_lshl_add_u32 %[t2], %[wd], 16, %[km]\n\t"              /* (2 * width - 1) << 15 */
-            "v_xor_b32_sdwa %[kff], %[wl], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
-            "v_ffbh_u32 %[c], %[t2]\n\t"
-            "v_lshlrev_b32 %[t], %[c], %[kff]\n\t"
-            "v_lshrrev_b32 %[t], 31, %[t]\n\t"
-            "v_add3_u32 %[n], %[c], %[t], -1"
-            : [wl] "+v"(wl), [wh] "+v"(wh), [kff] "+v"(kff), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
-            : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u)
-            : "vcc");
-        range = wd << n;
+    GPUAR_LANE void shift_and_store(uint32_t n) {
         {
             const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
             wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
@@ -676,13 +659,31 @@ struct CarryCoderLane {
             key = nff ? 0u : 0xFFFFFFFFu;
         }
 #endif
-#ifdef GPUAR_CARRY_JOIN_ASM
-        else {
-            // (no instruction: what the rare path may change is "redefined" on this side of the join as well, in place, so that the
-            // register allocator has no reason to copy it where the two sides meet)
-            asm volatile("" : "+v"(key), "+v"(nff), "+v"(at), "+v"(cache));
-        }
+    }
 #endif
+
+    GPUAR_LANE void step(uint32_t cums, Recip rc) {
+        const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
+        const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
+        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+#if defined(__HIP_DEVICE_COMPILE__)
+        // w += dn; n = renorm_count(w[15:0], wd) -- one statement: the xor lands in HALF a register (SDWA) and may be read
+        // by the second instruction behind it at the earliest (DESIGN.md 4.1 item 7), so the order is fixed here
+        uint32_t h, t2, c, t, n;
+        asm("v_add_co_u32 %[wl], vcc, %[wl], %[dn]\n\t"
+            "v_addc_co_u32 %[wh], vcc, 0, %[wh], vcc\n\t"
+            "v_add3_u32 %[h], %[wl], %[wd], -1\n\t"                   /* new hi, low 16 bits */
+            "v_lshl_add_u32 %[t2], %[wd], 16, %[km]\n\t"              /* (2 * width - 1) << 15 */
+            "v_xor_b32_sdwa %[kff], %[wl], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+            "v_ffbh_u32 %[c], %[t2]\n\t"
+            "v_lshlrev_b32 %[t], %[c], %[kff]\n\t"
+            "v_lshrrev_b32 %[t], 31, %[t]\n\t"
+            "v_add3_u32 %[n], %[c], %[t], -1"
+            : [wl] "+v"(wl), [wh] "+v"(wh), [kff] "+v"(kff), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
+            : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u)
+            : "vcc");
+        range = wd << n;
+        shift_and_store(n);
 #else
         const uint64_t sum = ((static_cast<uint64_t>(wh) << 32) | wl) + dn;
         const uint32_t n = renorm_count(static_cast<uint32_t>(sum) & 0xFFFFu, wd);
@@ -739,61 +740,69 @@ struct CarryCoderLane {
 };
 
 // ---------------------------------------------------------------------------
-// The coder cut in two, for the LATENCY-mode encoder (encode_small_kernel: inputs too small to fill the chip, where
-// the time of a launch is 8192 serial symbol steps of its slowest role and LDS is plentiful).  IntervalLane owns the
-// interval (applySymbolRange :256-299 and the closed-form renormalisation counts), SinkLane owns everything about
-// bits (pending underflow bits, accumulator, stores: writeEncodedBits' output side :321-367, writeRemaining :379-388,
-// writeClose :430-439).  They are joined by ONE word per symbol: the e agreed bits, e, u and bit 14 of the new lower
-// bound (what flush needs).  Same integers as CoderLane::step, cut at the line where `agreed` is formed.
+// The carry-form coder cut in two, for the LATENCY-mode encoder (encode_small_kernel; round 4: the owed-bits form's cut,
+// IntervalLane | SinkLane below, made the sink the longest role at ~34 instructions).  CarryIntervalLane owns the interval
+// -- applySymbolRange (:256-299) and the renormalisation count; of the lower bound it needs the live 16 bits only --,
+// CarrySinkLane owns the window, the held bits and the stores.  They are joined by ONE word per symbol: dn | n << 16
+// (what is added to the window, and by how much it then moves); nothing else, not even at the end of the packet
+// (the sink's window holds the true lower bound).  Same integers as CarryCoderLane::step.
 // ---------------------------------------------------------------------------
-struct IntervalLane {
-    uint32_t lo, range, kff;
+struct CarryIntervalLane {
+    uint32_t lo, range, kff;       // lo: the live lower bound in its low 16 bits (what is above them is ignored)
     GPUAR_LANE void open() {
         lo = 0;
         range = 0x10000u;
         kff = 0xFFFFu;
     }
-    // agreed bits [15:0] | e [23:16] | u [31:24]: whole bytes, so that the sink's instructions pick them out of the word
-    // by operand selects (SDWA) instead of extracting them.  (The sink also needs bit 14 of the LAST lower bound, once:
-    // the kernel hands `lo` over when the packet is through.)
     GPUAR_LANE uint32_t step(uint32_t cums, Recip rc) {
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
-        const uint32_t a = lo + dn;
         const uint32_t wd = up - dn;
-        const uint32_t h = a + wd - 1u;
-        uint32_t span;                                        // ~a | h
-        const uint32_t e = GPUAR_AGREE_COUNT(kff, a, h, span);
-        const uint32_t u = GPUAR_CLZ32_NZ(GPUAR_ALIGNBIT(span, 0xFFFFFFFFu, 15u - e));
-        const uint32_t shift = e + u;
-        lo = (a << shift) & 0x7FFFu;
-        range = wd << shift;
-        const uint32_t agreed = a >> (16u - e);                // 0 when e == 0 (a < 2^16)
-        return agreed | (e << 16) | (u << 24);
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t a, h, t2, c, t, n;
+        asm("v_add_u32 %[a], %[lo], %[dn]\n\t"
+            "v_add3_u32 %[h], %[a], %[wd], -1\n\t"
+            "v_lshl_add_u32 %[t2], %[wd], 16, %[km]\n\t"
+            "v_xor_b32_sdwa %[kff], %[a], %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+            "v_ffbh_u32 %[c], %[t2]\n\t"
+            "v_lshlrev_b32 %[t], %[c], %[kff]\n\t"
+            "v_lshrrev_b32 %[t], 31, %[t]\n\t"
+            "v_add3_u32 %[n], %[c], %[t], -1\n\t"
+            "v_lshlrev_b32_sdwa %[lo], %[n], %[a] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"   /* (a & 0xFFFF) << n */
+            : [lo] "+v"(lo), [kff] "+v"(kff), [a] "=&v"(a), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
+            : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u));
+#else
+        const uint32_t a = (lo + dn) & 0xFFFFu;
+        const uint32_t n = renorm_count(a, wd);
+        lo = a << n;
+#endif
+        range = wd << n;
+        return dn | (n << 16);
     }
 };
 
-struct SinkLane : CoderLane {
-    // final_lo: the interval lane's lower bound behind the packet's last symbol (finish() looks at its bit 14)
-    GPUAR_LANE uint32_t finish(uint32_t ulen, bool &overflowed, uint32_t final_lo) {
-        lo = final_lo;
-        return CoderLane::finish(ulen, overflowed);
-    }
+struct CarrySinkLane : CarryCoderLane {
     GPUAR_LANE void take(uint32_t packed) {
-        const uint32_t agreed = packed & 0xFFFFu, e = (packed >> 16) & 0xFFu, u = packed >> 24;
-        const uint32_t em1 = e - 1u;
-        const bool shift_out = e != 0u;
-        uint32_t bits = agreed + GPUAR_BFM(pending, em1);
-        uint32_t count = e + pending;
-        const bool long_run = shift_out & (pending > 16u);    // rare: more than 16 underflow bits owed
-        if (long_run) {
-            const uint32_t top = (agreed >> (em1 & 31u)) & 1u;
-            put_bit_then_run(top, pending);
-            bits = agreed & GPUAR_BFM(em1, 0u);
-            count = em1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t n;
+        asm("v_add_co_u32_sdwa %[wl], vcc, %[wl], %[p] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_addc_co_u32 %[wh], vcc, 0, %[wh], vcc\n\t"
+            "v_lshrrev_b32 %[n], 16, %[p]"
+            : [wl] "+v"(wl), [wh] "+v"(wh), [n] "=&v"(n)
+            : [p] "v"(packed)
+            : "vcc");
+        shift_and_store(n);
+#else
+        const uint32_t n = packed >> 16;
+        const uint64_t w = ((((static_cast<uint64_t>(wh) << 32) | wl) + (packed & 0xFFFFu)) << n);
+        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        held += n;
+        if (held >= 32u) {
+            uint32_t over;
+            const uint32_t word = take_top(over);
+            leave(word, over);
         }
-        put(shift_out ? bits : 0u, shift_out ? count : 0u);
-        pending = (shift_out ? 0u : pending) + u;
+#endif
     }
 };
 

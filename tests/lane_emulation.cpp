@@ -95,8 +95,8 @@ int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 }
 
 // The latency-mode encoder's five roles (encode_small_kernel): the tree dealt 3 + 3 + (0, 7, tail) to three modelers
-// that add their parts onto each other in phases of 8 symbols, the coder cut into IntervalLane and SinkLane joined
-// by one word per symbol.
+// that add their parts onto each other in phases of 8 symbols, the carry-form coder cut into CarryIntervalLane and
+// CarrySinkLane joined by one word per symbol (dn | n << 16).
 int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 {
     int any_overflow = 0;
@@ -113,9 +113,9 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
         upper.open(t, 0, in[off]);
         middle.open(t, 0, 0);
         low.open(t, 0, 0);
-        IntervalLane interval;
+        CarryIntervalLane interval;
         interval.open();
-        SinkLane sink;
+        CarrySinkLane sink;
         sink.open(slots, static_cast<uint32_t>(p * kSlot));
         for (uint32_t base = 0; base < len; base += kPhase) {
             const uint32_t count = len - base < kPhase ? len - base : kPhase;
@@ -141,7 +141,7 @@ int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
             for (uint32_t j = 0; j < count; ++j) sink.take(words[j]);
         }
         bool ov;
-        sink.finish(len, ov, interval.lo);
+        sink.finish(len, ov);
         any_overflow |= ov ? 1 : 0;
     }
     return any_overflow;
