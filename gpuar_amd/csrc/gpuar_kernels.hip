@@ -39,6 +39,16 @@
 namespace gpuar {
 
 __constant__ RecipTable g_recip = RecipTable();
+// The reciprocal multipliers alone, for the decoder (which fetches them eight at a time, two runs ahead, by vector loads
+// with a wave-uniform address); padded so that the look-ahead behind a packet's last symbols stays inside the table.
+struct MulTable {
+    uint32_t m[kPacket + 64];
+    constexpr MulTable() : m{} {
+        const RecipTable r = RecipTable();
+        for (uint32_t i = 0; i < kPacket + 64; ++i) m[i] = r.r[i < kPacket ? i : kPacket - 1u].mul;
+    }
+};
+__device__ const MulTable g_mul = MulTable();
 __constant__ DecodeConstTable g_decode = DecodeConstTable();
 __device__ uint32_t g_status = 0;
 __device__ uint32_t g_cu_ticket[2048];      // one arrival counter per CU (XCC, SE, SH, CU), see encode_kernel
@@ -648,7 +658,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #define GPUAR_A_HEAD \
             "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 /* off = the low half of lo : off */ \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
-            "v_add_u32 %[R0], %[totm1], %[R0]\n\t" /* off*total + total - 1 (total - 1: the previous symbol's total) */ \
+            "v_add3_u32 %[R0], %[R0], %[tbase], %[tj]\n\t" /* off*total + total - 1: total - 1 = (the run's first total - 1) + position, an inline constant */ \
             "v_sub_co_u32 %[t1], %[m0], %[R0], %[t0]\n\t" /* borrow = went left at depth 0 */ \
             "v_min_u32 %[R], %[R0], %[t1]\n\t" \
             "v_cndmask_b32 %[t2], %[h1], %[h0], %[m0]\n\t" /* the depth-1 node on the path */ \
@@ -666,8 +676,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             formed by that symbol's step); no field can carry into its neighbour (counts stay below 2^14).  And the last \
             instruction of the previous step's renormalisation: lo's top bit is cleared here, where it is needed next \
             (the head above reads only the lower half of lo : off) */ \
-            "ds_add_u64 %[oaddr], v[204:205]\n\t" \
-            "v_and_b32 v217, 0x7fffffff, v217\n\t"
+            "ds_add_u64 %[oaddr], v[204:205]\n\t"
 #define GPUAR_A_TAIL \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
@@ -806,7 +815,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx;
 
-#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_MUL, K_SHIFT, WORD, J) \
+#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD, J) \
     { \
         GPUAR_STEP_LOCALS \
         uint32_t lbw_, lcc_, ti_; \
@@ -814,8 +823,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1) \
-            : [tot] "s"((K_TOTAL)), [mul] "s"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [totm1] "s"((K_TOTAL) - 1u) \
+            : [tot] "s"((K_TOTAL)), [mul] "v"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
+              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [tbase] "s"((K_TOTAL0_M1)), [tj] "n"(POS) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
     }
 
@@ -875,14 +884,16 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // The step takes its stream dwords from a per-lane ring of 64 bytes in LDS, NOT from memory: a load from
     // memory that every symbol waits for (whichever lane asked for it) makes the symbol as long as a
     // round trip to L2, which at full load is LONGER than the step itself (~740 against ~600 cycles).
-    // The ring is refilled here, every four symbols, in pieces of 16 bytes that are asked for one phase
-    // (four symbols) before they are written to LDS: the vector-memory wait is for something issued
-    // ~2500 cycles ago.  Offsets are counted from base16 = base rounded down to 16 bytes, so pieces are
+    // The ring is refilled here, every eight symbols, in pieces of 16 bytes that are asked for one phase
+    // (eight symbols) before they are written to LDS: the vector-memory wait is for something issued
+    // ~4000 cycles ago.  Offsets are counted from base16 = base rounded down to 16 bytes, so pieces are
     // aligned (an aligned piece that holds one readable byte never crosses a page); past the end of what
     // may be read the last such piece is repeated (a well-formed packet decodes the same whatever follows).
-    // A lane consumes at most 31 bits per symbol = 15.5 bytes per phase, a phase brings 16: asking for
-    // piece P once the reader is within 48 bytes of it keeps >= 17 bytes in LDS ahead of the reader, and
-    // the piece P overwrites (P - 64) has been read completely by then.
+    // A lane consumes at most 16 bits per symbol (n = e + u <= 16: range' = width << n <= 2^16, whatever the
+    // bits are) = 16 bytes per phase of EIGHT symbols (rounds 1-3 reckoned with 31 bits and ran the phase every
+    // four), a phase brings 16: asking for piece P once the reader is within 48 bytes of it keeps >= 17 bytes in
+    // LDS ahead of the reader (the gap at a phase never falls below 33 bytes), and the piece P overwrites
+    // (P - 64) has been read completely by then.
     const uint32_t skew16 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) & 15u);
     const uint8_t *base16 = base - skew16;
     const uint32_t next16 = dec.next + skew16;                   // offset from base16 of the dword after `ahead` ...
@@ -910,7 +921,13 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // slots per four symbols): the piece asked for last is (re)written to its place, then the lanes whose reader
     // is within 48 bytes of `fill` ask for the next piece -- a predicated region without a branch around it.
     // s_waitcnt vmcnt(0): the piece was asked for a phase ago; the block's output stores drain here as well.
-#define GPUAR_RING_PHASE                                                                                             \
+// ... and, since round 4, the reciprocal multipliers of the run AFTER NEXT: eight dwords by two loads with a wave-uniform
+// address (`mulbase` = the half block's first multiplier, a scalar pair; OFF = byte offset of that run) that put the same
+// value into every lane of the eight registers of set SET (v224 + 8 * SET ..., named in the text as two tuples; the compiler
+// knows them as the pinned variables m<SET>0..7) -- where the step's two v_mul_hi_u32 take it from directly.  The
+// loads land before the next phase's s_waitcnt vmcnt(0), one whole run before they are used.  (Rounds 2-3 kept symbol j's
+// multiplier in lane j of ONE register per block of 64 and fetched it with a v_readlane per symbol.)
+#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI)                                                        \
     {                                                                                                                \
         uint32_t t_, t2_;                                                                                            \
         unsigned long long sx_;                                                                                      \
@@ -918,6 +935,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             "s_waitcnt vmcnt(0)\n\t"                                                                                 \
             "ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                                    \
             "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t"                                          \
+            "global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[off]\n\t"                                \
+            "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[off]+16\n\t"                             \
             "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
             "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
             "v_cmp_gt_u32 vcc, 49, %[t]\n\t"                                                                         \
@@ -929,59 +948,68 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             "v_add_u32 %[fill], 16, %[fill]\n\t"                                                                     \
             "s_or_b64 exec, exec, %[sx]"                                                                             \
             : [slot] "+v"(slot_lds), [fill] "+v"(fill), [t] "=&v"(t_), [t2] "=&v"(t2_), [sx] "=&s"(sx_),             \
-              "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)                                                                 \
-            : [next] "v"(next64), [lastp] "v"(last_piece), [base] "s"(base16), [ring] "v"(ring_lds)                  \
+              "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "=v"(m##SET##0), "=v"(m##SET##1), "=v"(m##SET##2), "=v"(m##SET##3), \
+              "=v"(m##SET##4), "=v"(m##SET##5), "=v"(m##SET##6), "=v"(m##SET##7)                                     \
+            : [next] "v"(next64), [lastp] "v"(last_piece), [base] "s"(base16), [ring] "v"(ring_lds),                 \
+              [zero] "v"(vzero), [mulbase] "s"(mul_base), [off] "n"(OFF)                                             \
             : "vcc", "memory");                                                                                      \
     }
 
-    // The per-symbol reciprocals (Recip: 8 bytes per symbol, wave-uniform) reach the symbol step WITHOUT scalar
-    // loads: one coalesced vector load per block of 64 symbols puts symbol j's pair into lane j of two
-    // registers, a whole block ahead, and each step picks its pair with two v_readlane; the model total is
-    // simply counted up.  Scalar loads were the costliest thing in this loop: a scalar load that misses its
-    // cache goes to L2 like everything else, and while 1024 wavefronts stream their packets in and their
+    // The per-symbol reciprocal multipliers (wave-uniform) reach the symbol step WITHOUT scalar loads and -- since round 4 --
+    // without a v_readlane: the ring phase above fetches the eight of the run after next into registers by vector loads
+    // with a wave-uniform address (every lane gets the same dword), four sets of eight registers taking turns; the shift
+    // that goes with a multiplier is the same for all 64 symbols of a block (RecipTable) and follows from the block's first
+    // total; the model total is simply counted up.  Scalar loads were the costliest thing in this loop: a scalar load that
+    // misses its cache goes to L2 like everything else, and while 1024 wavefronts stream their packets in and their
     // output out that round trip is thousands of cycles; it counts in lgkmcnt with the LDS operations, can
     // only be waited for with lgkmcnt(0), and even issued eight symbols ahead of its use it cost ~80 of
     // ~720 cycles per symbol (one group ahead: ~175 of 830; measured by taking the table walk out,
     // tools/kind_timing.py).  The waits of the symbol step have the form "an LDS read, one LDS operation
     // behind it, s_waitcnt lgkmcnt(1)", which holds whatever else is in flight.
-    const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    Recip recip_now, recip_next = g_recip.r[lane_id];                       // lane j: the pair of symbol i + j
-    // (every lane takes part in this rotation, also one that sits the block out: it may hold the pair of a symbol)
-#define GPUAR_ROTATE_RECIPS                                                                                          \
-    {                                                                                                                \
-        recip_now = recip_next;                                                                                      \
-        const uint32_t ahead_at = i + 64u + lane_id;                                                                 \
-        recip_next = g_recip.r[ahead_at < kPacket ? ahead_at : kPacket - 1u];                                        \
-    }
-// The lane select of v_readlane_b32 is the low six bits of its scalar operand, and the model total of symbol
-// i + j is 256 + i + j with i a multiple of 64: the total itself selects lane j (no separate index to count up).
-#define GPUAR_MUL_OF(TOTAL) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.mul), static_cast<int>(TOTAL)))
-#define GPUAR_SHIFT_OF(J) block_shift   /* the same for all 64 symbols of a block, see RecipTable */
+    // four sets of eight pinned registers, v224 + 8 * set + j: set s holds the multipliers of run s of a half block
+    register uint32_t m00 asm("v224"); register uint32_t m01 asm("v225"); register uint32_t m02 asm("v226"); register uint32_t m03 asm("v227"); register uint32_t m04 asm("v228"); register uint32_t m05 asm("v229"); register uint32_t m06 asm("v230"); register uint32_t m07 asm("v231");
+    register uint32_t m10 asm("v232"); register uint32_t m11 asm("v233"); register uint32_t m12 asm("v234"); register uint32_t m13 asm("v235"); register uint32_t m14 asm("v236"); register uint32_t m15 asm("v237"); register uint32_t m16 asm("v238"); register uint32_t m17 asm("v239");
+    register uint32_t m20 asm("v240"); register uint32_t m21 asm("v241"); register uint32_t m22 asm("v242"); register uint32_t m23 asm("v243"); register uint32_t m24 asm("v244"); register uint32_t m25 asm("v245"); register uint32_t m26 asm("v246"); register uint32_t m27 asm("v247");
+    register uint32_t m30 asm("v248"); register uint32_t m31 asm("v249"); register uint32_t m32 asm("v250"); register uint32_t m33 asm("v251"); register uint32_t m34 asm("v252"); register uint32_t m35 asm("v253"); register uint32_t m36 asm("v254"); register uint32_t m37 asm("v255");
+    uint32_t vzero;                                             // (a zero the compiler does not know: the loads' vector offset)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+// Eight symbols (two output words) and the ring phase behind them; RUN (0..3) is the run's static position in the half block.
+#define GPUAR_DECODE_RUN8(RUN, WORD_A, WORD_B, SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
+        {                                                                                                            \
+            const uint32_t j0 = 32u * half + 8u * (RUN); /* wave-uniform: first symbol of this run inside the block */ \
+            const uint32_t total0 = 256u + i + j0;                                                                   \
+            const uint32_t total0_m1 = 255u + i + j0; /* each step adds its position in the run as an inline constant */ \
+            /* every step writes its symbol into its own byte of the word (the step's last instruction) */          \
+            GPUAR_DECODE_SYMBOL(total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A, 0)                             \
+            GPUAR_DECODE_SYMBOL(total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A, 1)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A, 2)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A, 3)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B, 0)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B, 1)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B, 2)                        \
+            GPUAR_DECODE_SYMBOL(total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B, 3)                        \
+            /* ... and fetches the multipliers of the run after next: 8 * (RUN + 2) dwords behind the half block's first */ \
+            GPUAR_RING_PHASE(32 * ((RUN) + 2), SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
+        }
+// A block of 64 symbols as two half blocks of 32: the loop body is 32 symbols long, so every output word has a register
+// of its own by name -- rounds 1-3 looped over runs of eight and filed each word into a register array by index (a
+// v_not, an s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off and a scalar add per word, 1.5 issue slots per symbol, plus
+// the loop's own six per eight symbols).  The 32 bytes leave as two back-to-back 16-byte stores: a whole 32-byte sector.
+// (The path bits are the COMPLEMENTED symbol bits: the words are complemented where they are stored.)
 #define GPUAR_DECODE_BLOCK                                                                                           \
     {                                                                                                                \
-        uint32_t block[16], word;                                                                                    \
-        asm volatile("v_mov_b32 %0, 0" : "=v"(word));   /* (defined before the first byte goes in) */                \
-        const uint32_t block_shift = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(recip_now.shift), 0)); \
-        _Pragma("unroll 1") for (uint32_t g = 0; g < 16u; g += 2u) {                                                 \
-            const uint32_t j0 = 4u * g; /* wave-uniform: first symbol of this run inside the block */               \
-            const uint32_t total0 = 256u + i + j0;                                                                   \
-            /* every step writes its symbol into its own byte of the word (the step's last instruction) */              \
-            GPUAR_DECODE_SYMBOL(total0, GPUAR_MUL_OF(total0), GPUAR_SHIFT_OF(j0), word, 0)                               \
-            GPUAR_DECODE_SYMBOL(total0 + 1u, GPUAR_MUL_OF(total0 + 1u), GPUAR_SHIFT_OF(j0 + 1u), word, 1)                \
-            GPUAR_DECODE_SYMBOL(total0 + 2u, GPUAR_MUL_OF(total0 + 2u), GPUAR_SHIFT_OF(j0 + 2u), word, 2)                \
-            GPUAR_DECODE_SYMBOL(total0 + 3u, GPUAR_MUL_OF(total0 + 3u), GPUAR_SHIFT_OF(j0 + 3u), word, 3)                \
-            block[g] = ~word; /* the path bits are the COMPLEMENTED symbol bits */                                   \
-            GPUAR_RING_PHASE                                                                                         \
-            GPUAR_DECODE_SYMBOL(total0 + 4u, GPUAR_MUL_OF(total0 + 4u), GPUAR_SHIFT_OF(j0 + 4u), word, 0)                \
-            GPUAR_DECODE_SYMBOL(total0 + 5u, GPUAR_MUL_OF(total0 + 5u), GPUAR_SHIFT_OF(j0 + 5u), word, 1)                \
-            GPUAR_DECODE_SYMBOL(total0 + 6u, GPUAR_MUL_OF(total0 + 6u), GPUAR_SHIFT_OF(j0 + 6u), word, 2)                \
-            GPUAR_DECODE_SYMBOL(total0 + 7u, GPUAR_MUL_OF(total0 + 7u), GPUAR_SHIFT_OF(j0 + 7u), word, 3)                \
-            block[g + 1u] = ~word;                                                                                   \
-            GPUAR_RING_PHASE                                                                                         \
+        /* the shift that goes with the multipliers: floor(log2(total)) - 1, the same for all 64 totals of a block */ \
+        const uint32_t block_shift = 30u - static_cast<uint32_t>(__builtin_clz(256u + i));                           \
+        _Pragma("unroll 1") for (uint32_t half = 0; half < 2u; ++half) {                                             \
+            const uint32_t *mul_base = g_mul.m + i + 32u * half; /* wave-uniform: a scalar pair */                  \
+            GPUAR_DECODE_RUN8(0, w0, w1, 2, "v[240:243]", "v[244:247]")                                              \
+            GPUAR_DECODE_RUN8(1, w2, w3, 3, "v[248:251]", "v[252:255]")                                              \
+            GPUAR_DECODE_RUN8(2, w4, w5, 0, "v[224:227]", "v[228:231]")                                              \
+            GPUAR_DECODE_RUN8(3, w6, w7, 1, "v[232:235]", "v[236:239]")                                              \
+            uint4 *dst = reinterpret_cast<uint4 *>(out + i + 32u * half);                                            \
+            dst[0] = make_uint4(~w0, ~w1, ~w2, ~w3);                                                                 \
+            dst[1] = make_uint4(~w4, ~w5, ~w6, ~w7);                                                                 \
         }                                                                                                            \
-        uint4 *dst = reinterpret_cast<uint4 *>(out + i);                                                             \
-        _Pragma("unroll") for (uint32_t v = 0; v < 4; ++v)                                                           \
-            dst[v] = make_uint4(block[4 * v], block[4 * v + 1], block[4 * v + 2], block[4 * v + 3]);                 \
     }
 
     // ---- blocks that every lane of the wavefront owns: uniform control flow ----
@@ -990,20 +1018,30 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // next step's first read); nothing is owed yet: an add of zero to the half reset() named.
     // (Initial values go through asm: a known constant would be spliced into the statements as an immediate.)
     asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(o0), "=v"(o1));
+    // the eight output words of a half block (every byte of each is written before it is read; defined once for the compiler)
+    uint32_t w0, w1, w2, w3, w4, w5, w6, w7;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\tv_mov_b32 %4, 0\n\tv_mov_b32 %5, 0\n\tv_mov_b32 %6, 0\n\tv_mov_b32 %7, 0"
+                 : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(w4), "=v"(w5), "=v"(w6), "=v"(w7));
+    // the multipliers of the packet's first two runs (symbols 0..15); from then on every run fetches those of the run after next
+    asm volatile("global_load_dwordx4 v[224:227], %[zero], %[mulbase]\n\t"
+                 "global_load_dwordx4 v[228:231], %[zero], %[mulbase] offset:16\n\t"
+                 "global_load_dwordx4 v[232:235], %[zero], %[mulbase] offset:32\n\t"
+                 "global_load_dwordx4 v[236:239], %[zero], %[mulbase] offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=v"(m00), "=v"(m01), "=v"(m02), "=v"(m03), "=v"(m04), "=v"(m05), "=v"(m06), "=v"(m07),
+                   "=v"(m10), "=v"(m11), "=v"(m12), "=v"(m13), "=v"(m14), "=v"(m15), "=v"(m16), "=v"(m17)
+                 : [zero] "v"(vzero), [mulbase] "s"(static_cast<const uint32_t *>(g_mul.m))
+                 : "memory");
     for (; i + 64u <= len_min; i += 64u) {
-        GPUAR_ROTATE_RECIPS
         GPUAR_DECODE_BLOCK
     }
     // ---- the remaining whole blocks of a wavefront whose lanes differ in length (the file's short last packet,
     //      dead lanes of the last wavefront): lanes that do not own the block sit it out ----
     for (; i + 64u <= len_max; i += 64u) {
-        GPUAR_ROTATE_RECIPS
         if (i + 64u <= dec.ulen) GPUAR_DECODE_BLOCK
     }
 #undef GPUAR_DECODE_BLOCK
-#undef GPUAR_MUL_OF
-#undef GPUAR_SHIFT_OF
-#undef GPUAR_ROTATE_RECIPS
+#undef GPUAR_DECODE_RUN8
 #undef GPUAR_RING_PHASE
     // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
     // (and a piece the last ring phase asked for may still be on its way into v220-v223)
