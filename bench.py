@@ -264,7 +264,7 @@ def measure_copy_peak(H, d_src, d_dst, n_bytes, reps=10):
     ms = timed_kernel_ms(lambda: H.device_copy(d_src, d_dst, n), reps)
     best, avg = min(ms), sum(ms) / len(ms)
     return {"GBps": 2 * n / (avg * 1e-3) / 1e9, "best_GBps": 2 * n / (best * 1e-3) / 1e9, "ms_avg": avg, "reps": reps,
-            "bytes_copied": n, "kernel": "copy_kernel (gpuar_hip_copy): 16 B per lane, read + write counted",
+            "bytes_copied": n, "kernel": "copy_kernel (gpuar_hip_copy): 16 B per lane, one quad per thread, read + write counted",
             "frac_of_datasheet_peak": 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
 

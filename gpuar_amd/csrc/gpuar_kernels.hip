@@ -1290,20 +1290,16 @@ generate_zipf_kernel(uint64_t seed, uint64_t first_word, size_t n, uint8_t *__re
 }
 
 // ---------------------------------------------------------------------------
-// The roof bench.py quotes next to the datasheet's: a plain device-to-device copy, 16 bytes per lane, every
-// wavefront-instruction a contiguous 1 KiB, four loads in flight per lane before the first store (SURVEY.md section 8(d):
-// "confirm a practical peak on the box with a device-to-device copy and report both").  Measurement support, not
-// part of the codec path.
+// The roof bench.py quotes next to the datasheet's: a plain device-to-device copy, 16 bytes per lane, ONE quad per thread
+// and one 4 KiB tile per workgroup ("confirm a practical peak on the box with a device-to-device
+// copy and report both").  Of the shapes tried (tools/copy_probe.hip, profiles/r04_copy_probe.txt: hipMemcpyAsync 4.8 TB/s,
+// grid-stride loops with 4-8 loads in flight 4.7-5.2, tiles of 4 or 8 quads per thread 3.7-5.6) this, the simplest one,
+// is the fastest: 6.18 TB/s read + write on 8 GiB.  Measurement support, not part of the codec path.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_quads) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * 256u;
-    size_t q = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
-    for (; q + 3u * stride < n_quads; q += 4u * stride) {
-        const uint4 a = src[q], b = src[q + stride], c = src[q + 2u * stride], d = src[q + 3u * stride];
-        dst[q] = a, dst[q + stride] = b, dst[q + 2u * stride] = c, dst[q + 3u * stride] = d;
-    }
-    for (; q < n_quads; q += stride) dst[q] = src[q];
+    const size_t q = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (q < n_quads) dst[q] = src[q];
 }
 
 }  // namespace gpuar
@@ -1481,8 +1477,9 @@ int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *s
     if (!d_src || !d_dst || (n_bytes & 15u)) return GPUAR_ERR_ARGUMENT;
     if (!aligned16(d_src) || !aligned16(d_dst)) return GPUAR_ERR_ALIGNMENT;
     const size_t n_quads = n_bytes / 16u;
-    const size_t want = (n_quads + 1023u) / 1024u;                  // four quads per thread
-    const uint32_t blocks = static_cast<uint32_t>(want < 1u ? 1u : (want > 8192u ? 8192u : want));   // 32 workgroups per CU at most
+    const size_t want = (n_quads + 255u) / 256u;                    // one quad per thread
+    if (want > 0x7FFFFFFFull) return GPUAR_ERR_ARGUMENT;             // 8 TiB: beyond any device
+    const uint32_t blocks = static_cast<uint32_t>(want);
     gpuar::copy_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(d_dst), n_quads);
     return check_launch();
