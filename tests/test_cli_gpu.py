@@ -82,6 +82,37 @@ def test_gpu_cli_shards_over_several_devices(tmp_path):
     assert r.returncode == 1 and "visible" in r.stderr
 
 
+def test_gpu_cli_deals_equal_shares_to_eight_devices(tmp_path):
+    """--gpus=8 (eight logical devices oversubscribed onto this box's one, ONE process): the file is cut into contiguous
+    packet ranges sized so that every lane of every device gets one, dealt round-robin in file order (DESIGN.md section 6);
+    GPUAR_TRACE names what every device coded.  All eight devices work, their shares differ by one chunk at most, the
+    bytes add up -- and the file equals the single-device file."""
+    import re
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, g1, g8, back = tmp_path / "in.dat", tmp_path / "one.gip", tmp_path / "eight.gip", tmp_path / "back.dat"
+    n = 256 * 1024 * 1024 + 12345                               # a quarter GiB: 32769 packets
+    synth.uniform(17, n).tofile(src)
+    assert run("c", f"--in={src}", f"--out={g1}").returncode == 0
+    env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1", GPUAR_TRACE="1")
+    for mode, out, inp in (("c", g8, src), ("d", back, g8)):
+        r = subprocess.run([CLI, mode, f"--in={inp}", f"--out={out}", "--gpus=8"], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        verb = "coded" if mode == "c" else "decoded"
+        shares = [(int(d), int(b), int(k)) for d, b, k in re.findall(rf"device (\d+) {verb} (\d+) bytes in (\d+) chunks", r.stderr)]
+        assert [d for d, _, _ in shares] == list(range(8)), r.stderr[-2000:]
+        assert sum(b for _, b, _ in shares) == n
+        assert all(b > 0 for _, b, _ in shares)                                  # every device works
+        chunks = [k for _, _, k in shares]
+        assert max(chunks) - min(chunks) <= 1                                    # the same number of chunks to within one
+        if mode == "c":
+            cap = int(re.search(r"chunks of at most (\d+) bytes", r.stderr).group(1))
+            assert cap % (64 * 8192) == 0 and cap <= -(-n // (8 * 3 * 64 * 8192)) * 64 * 8192     # <= ceil(share of a lane), whole wavefronts
+            assert max(b for _, b, _ in shares) - min(b for _, b, _ in shares) <= cap     # shares differ by one chunk at most
+    assert g8.read_bytes() == g1.read_bytes()
+    assert back.read_bytes() == src.read_bytes()
+
+
 def test_gpu_cli_index_trailer_and_bulk_reads(tmp_path):
     """--index on the GPU path: same bytes as the host writes, trailer a pure suffix; decode with and
     without the index, in several rounds (read windows that cut packets), on 1 and on 3 (oversubscribed) devices."""

@@ -510,6 +510,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["decode_stream_roundtrip_equal"] is True
 
 
+def test_bench_five_rank_dry_run_on_one_gpu(tmp_path):
+    """The widest dry run this pool allows: a one-GPU box admits SIX processes on its card at once (more are killed by
+    its process guard) and this test process is one of them, so `bench.py --gpus 5` is self-launched with all five ranks
+    oversubscribed onto the one GPU -- the N > 2 flow of the line the driver's 8-GPU run will print: n_ranks_seen, one
+    compressed size per rank, per-rank kernel times, the other scaling mode and the gather probe, all over five ranks.
+    (Eight ranks: the CPU rehearsal in tests/test_sharding_gloo.py.)"""
+    import subprocess
+    import sys
+    world = 5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--gib-per-gpu", "0.125", "--total-gib", "0.625", "--no-cpu-baseline", "--no-small-config"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["n_ranks_seen"] == world and d["scaling"] == "weak"
+    assert d["roundtrip_equal"] is True and d["device_status"] == 0
+    assert len(d["per_rank"]["compressed_bytes"]) == world and all(c > 0 for c in d["per_rank"]["compressed_bytes"])
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - world * 0.125 * 1.073741824) < 1e-6
+    assert d["other_scaling"]["scaling"] == "strong" and d["other_scaling"]["roundtrip_equal"] is True
+    assert d["other_scaling"]["total_bytes"] == world * (1 << 27)
+    assert d["gather_probe"]["ranks"] == world and d["gather_probe"]["cheaper"] in ("staged hipMemcpyAsync", "RCCL gather")
+    assert "hbm_copy_peak" in d and d["roofline"]["peak_measured_copy"] > 0
+
+
 def test_bench_strong_scaling_splits_one_stream(tmp_path):
     """configs[3] in miniature: a fixed total split into contiguous packet ranges, one per rank."""
     d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5", "--gib-per-gpu", "0.25"], tmp_path)

@@ -69,3 +69,54 @@ def test_two_rank_segments_concatenate_to_the_whole_stream(kind, n):
     assert hashlib.md5(joined).hexdigest() == hashlib.md5(whole.tobytes()).hexdigest()
     assert got[0][2] == got[1][2] == [len(got[0][1]), len(got[1][1])]     # all_gather of segment sizes
     assert got[0][3] == got[1][3] == 1.5                                  # MAX over ranks
+
+
+def _worker8(rank, world, port, q):
+    """One of EIGHT ranks of bench.py's control plane on CPU: bench.plan_shard for both scaling modes, bench.gather_rows
+    (the all_gather of one row per rank) and the MAX of the elapsed time -- the code paths `bench.py --gpus 8` takes around
+    its kernels, here with the oracle standing in for the device on a small shard."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle import oracle as O
+    cpu = torch.device("cpu")
+    total = 8 * 64 * 8192 + 5000                                      # configs[3] in miniature: one stream over 8 ranks
+    args = bench.parse_args(["--gpus", "8", "--scaling", "strong", "--total-gib", str(total / (1 << 30))])
+    off, n = sharding.plan_shards(total, world)[rank]
+    weak = bench.plan_shard(bench.parse_args(["--gpus", "8", "--gib-per-gpu", "0.125"]), world, rank)
+    seg = O.PortOracle().encode_stream(synth.generate("uniform", 42, n, offset=off))
+    rows = bench.gather_rows(dist, world, cpu, [1, int(seg.size), n, 1, 1000 + rank, 2000 + rank])
+    t = torch.tensor([0.25 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, rows, weak, float(t.item()), hashlib.md5(seg.tobytes()).hexdigest(), args.scaling))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_control_plane_on_cpu():
+    """No 8-GPU node is available to the build (and a one-GPU box admits six GPU processes at most), so the eight-rank
+    flow of bench.py is rehearsed here over gloo: every rank sees eight rows in rank order, the shards tile the stream,
+    the MAX of the times is the slowest rank's, and the segments concatenate to the single-process stream."""
+    from oracle import oracle as O
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = 8 * 64 * 8192 + 5000
+    rows0 = got[0][1]
+    assert all(g[1] == rows0 for g in got) and len(rows0) == world
+    assert sum(r[3] for r in rows0) == world                           # n_ranks_seen
+    assert sum(r[2] for r in rows0) == total and [r[4] for r in rows0] == [1000 + k for k in range(world)]
+    assert [g[2] for g in got] == [(k << 27, 1 << 27) for k in range(world)]      # weak shards: rank r owns [r*B, (r+1)*B)
+    assert all(g[3] == 2.0 for g in got)                               # MAX over ranks
+    whole = O.PortOracle().encode_stream(synth.generate("uniform", 42, total))
+    assert sum(r[1] for r in rows0) == whole.size                      # the segment sizes add up to the whole stream's
