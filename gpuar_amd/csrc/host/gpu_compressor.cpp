@@ -129,23 +129,46 @@ class MappedInput {
         size = bytes;
         (void)::madvise(m, bytes, MADV_SEQUENTIAL);
         state.assign((bytes + kWindow - 1) / kWindow, 0);
+        users.assign(state.size(), 0);
+        live = 0;
+        if (const char *cap = std::getenv("GPUAR_MAX_WINDOWS")) max_live = std::max<size_t>(1, std::strtoul(cap, nullptr, 10));
     }
-    // makes [at, at + n) DMA-able; false: this file cannot be registered (the caller reads it with pread instead)
+    // makes [at, at + n) DMA-able and counts the caller as a user of its windows until release(at, n);
+    // false: this file cannot be registered (the caller reads it with pread instead, and owes no release)
     bool require(uint64_t at, size_t n) {
         if (!base || n == 0) return base != nullptr;
         std::lock_guard<std::mutex> hold(lock);
         if (refused) return false;
-        for (size_t w = at / kWindow; w <= (at + n - 1) / kWindow; ++w) {
+        const size_t first = at / kWindow, last = (at + n - 1) / kWindow;
+        for (size_t w = first; w <= last; ++w) {
             if (state[w]) continue;
             const size_t begin = w * kWindow, len = std::min(kWindow, size - begin);
             if (hipHostRegister(const_cast<uint8_t *>(base) + begin, len, hipHostRegisterPortable) != hipSuccess) {
                 (void)hipGetLastError();
-                refused = true;
-                return false;
+                refused = true;       // e.g. the memlock / userptr limit: from here on everybody reads with pread
+                return false;         // (windows registered so far stay until their users are done)
             }
             state[w] = 1;
+            ++live;
         }
+        for (size_t w = first; w <= last; ++w) ++users[w];
         return true;
+    }
+    // the copies out of [at, at + n) have completed (the caller synchronised its stream).  Windows nobody uses any more
+    // are unregistered, oldest first, once more than `max_live` are registered: the registered (pinned, DMA-mapped)
+    // footprint of a job stays at max_live * 256 MiB however large the file is, instead of growing to the whole input.
+    void release(uint64_t at, size_t n) {
+        if (!base || n == 0) return;
+        std::lock_guard<std::mutex> hold(lock);
+        for (size_t w = at / kWindow; w <= (at + n - 1) / kWindow; ++w)
+            if (users[w]) --users[w];
+        for (size_t w = 0; w < state.size() && live > max_live; ++w)
+            if (state[w] && !users[w]) {
+                (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
+                state[w] = 0;
+                --live;
+                ++trimmed;
+            }
     }
     void close() {
         if (warmer.joinable()) warmer.join();
@@ -155,6 +178,8 @@ class MappedInput {
         ::munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
         state.clear();
+        users.clear();
+        live = 0;
         refused = false;
     }
     // registers the first window on a thread of its own (the first registration of a process costs ~35 ms, as long as a lane
@@ -162,12 +187,21 @@ class MappedInput {
     void warmFirstWindow(int device) {
         if (!base) return;
         warmer = std::thread([this, device] {
-            if (hipSetDevice(device) == hipSuccess) (void)require(0, std::min(kWindow, size));
+            const size_t n = std::min(kWindow, size);
+            if (hipSetDevice(device) == hipSuccess && require(0, n)) release(0, n);
         });
     }
     const uint8_t *data() const { return base; }
     // a copy must not straddle two registrations: the end of the window `at` lies in
     static size_t windowEnd(uint64_t at) { return (at / kWindow + 1) * kWindow; }
+    size_t windowsTrimmed() {
+        std::lock_guard<std::mutex> hold(lock);
+        return trimmed;
+    }
+    bool wasRefused() {
+        std::lock_guard<std::mutex> hold(lock);
+        return refused;
+    }
 
   private:
     static constexpr size_t kWindow = 256u << 20;
@@ -176,6 +210,10 @@ class MappedInput {
     size_t size = 0;
     std::mutex lock;
     std::vector<uint8_t> state;      // per window: registered?
+    std::vector<uint32_t> users;     // per window: chunks whose copies out of it may still be in flight
+    size_t live = 0;                 // registered windows
+    size_t max_live = 16;            // ... of which at most this many are kept once nobody uses them (4 GiB; GPUAR_MAX_WINDOWS)
+    size_t trimmed = 0;
     bool refused = false;
 };
 
@@ -425,14 +463,16 @@ struct GPUCompressor::DeviceBuffers {
 
     // `n` bytes of the input file at `at` -> dst (device): straight from the mapping when there is one, else through
     // the lane's pinned pieces
-    void upload(uint8_t *dst, MappedInput &in, int fd, uint64_t at, size_t n, const char *error) {
+    // Returns true when the copies were queued straight out of the mapping: the caller then owes in.release(at, n)
+    // once it has synchronised this lane's stream.
+    bool upload(uint8_t *dst, MappedInput &in, int fd, uint64_t at, size_t n, const char *error) {
         if (in.data() && in.require(at, n)) {
             for (size_t done = 0; done < n;) {           // one copy per registered window
                 const size_t part = std::min<uint64_t>(n - done, MappedInput::windowEnd(at + done) - (at + done));
                 hip_check(hipMemcpyAsync(dst + done, in.data() + at + done, part, hipMemcpyHostToDevice, stream), "H2D");
                 done += part;
             }
-            return;
+            return true;
         }
         for (size_t done = 0; done < n;) {
             const size_t k = takePiece();
@@ -448,6 +488,7 @@ struct GPUCompressor::DeviceBuffers {
             givePiece(k);
             done += part;
         }
+        return false;
     }
 
     // src[0..n) (device) -> the writer, piece by piece; `at`: file offset of the first byte (unordered writer).
@@ -611,7 +652,17 @@ void GPUCompressor::runLanes(Work &&work, OnFailure &&on_failure) {
             }
         });
     for (auto &t : threads) t.join();
-    if (failure.first) std::rethrow_exception(failure.first);
+    if (failure.first) {
+        // A lane that failed may have left copies out of the mapped input queued on its stream; the caller's unwinding
+        // unregisters and unmaps that file next.  Nothing may still be reading it: drain every lane's stream first
+        // (results ignored -- the failure that is about to be reported is the first one).
+        for (DeviceBuffers *b : buffers)
+            if (b->cap && b->stream) {
+                (void)hipSetDevice(b->device);
+                (void)hipStreamSynchronize(b->stream);
+            }
+        std::rethrow_exception(failure.first);
+    }
 }
 
 CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
@@ -680,10 +731,11 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                             b.epoch = static_cast<hipEvent_t>(epochOf(g));
                             const uint64_t at = chunk_at[c];
                             const size_t n_plain = static_cast<size_t>(chunk_at[c + 1] - at);
-                            b.upload(b.d_plain, mapped, in_fd, at, n_plain, "Read input file failed");
+                            const bool from_mapping = b.upload(b.d_plain, mapped, in_fd, at, n_plain, "Read input file failed");
                             if (c == 0) trace("compress: its input on its way (window registered, copy queued)");
                             uint32_t flags = 0;
-                            const size_t n_stream = b.encodeChunk(n_plain, flags, encode_mode);
+                            const size_t n_stream = b.encodeChunk(n_plain, flags, encode_mode);     // (synchronises the lane's stream)
+                            if (from_mapping) mapped.release(at, n_plain);
                             if (c < 3) trace("compress: kernels of an early chunk done, chunk", static_cast<double>(c));
                             if (flags & GPUAR_STATUS_SLOT_OVERFLOW)
                                 throw std::runtime_error("a packet outgrew its 8704-byte slot (input bytes " + std::to_string(at) + " .. " +
@@ -709,6 +761,8 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                 std::rethrow_exception(lane_failure);
             }
             trace("compress: lanes done");
+            trace(mapped.wasRefused() ? "compress: a window could not be registered: the rest was read with pread" : "compress: every window registered");
+            trace("compress: input windows unregistered while the job ran:", static_cast<double>(mapped.windowsTrimmed()));
             for (size_t g = 0; g < G; ++g)
                 trace(("compress: device " + std::to_string(g) + " coded " + std::to_string(device_bytes[g].load()) + " bytes in " +
                        std::to_string(device_chunks[g].load()) + " chunks of at most " + std::to_string(chunkPackets * kPacket) + " bytes").c_str());
@@ -961,8 +1015,12 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
             });
         }
 
-        // what the packet count promises, allocated up front (best effort); the real length is set at the end
-        (void)::fallocate(out_fd, 0, 0, static_cast<off_t>(static_cast<uint64_t>(expect_packets) * kPacket));
+        // what the packet count promises, allocated up front (best effort); the real length is set at the end.  A header
+        // may claim anything up to 2048 times the stream's size (a packet is at least 4 bytes): the preallocation is bounded
+        // by what packets can plausibly hold -- 64 times the stream (8192 zeros code to 210 bytes, 39 times) -- and the file
+        // simply grows beyond that if the packets really say so.
+        const size_t prealloc_packets = std::min(expect_packets, 64 * at_least);
+        (void)::fallocate(out_fd, 0, 0, static_cast<off_t>(static_cast<uint64_t>(prealloc_packets) * kPacket));
         OrderedOffsets place;
         std::vector<std::atomic<size_t>> next_of_device(G);
         for (auto &n : next_of_device) n = 0;
@@ -995,7 +1053,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                             hip_check(hipSetDevice(b.device), "hipSetDevice");
                             b.epoch = static_cast<hipEvent_t>(epochOf(g));
                             const size_t n_stream = static_cast<size_t>(chunk.end - chunk.begin);
-                            b.upload(b.d_stream, mapped, in_fd, chunk.begin, n_stream, "Invalid file length");
+                            const bool from_mapping = b.upload(b.d_stream, mapped, in_fd, chunk.begin, n_stream, "Invalid file length");
                             const uint8_t *bytes = mapped.data() ? mapped.data() + chunk.begin : nullptr;
                             if (!bytes) {
                                 staged.resize(n_stream);
@@ -1025,7 +1083,8 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                             const uint64_t out_at = place.take(c, produced);
                             device_bytes[g] += produced;
                             device_chunks[g] += 1;
-                            const uint32_t flags = b.decodeChunk(chunk.n_packets);
+                            const uint32_t flags = b.decodeChunk(chunk.n_packets);        // (synchronises the lane's stream)
+                            if (from_mapping) mapped.release(chunk.begin, n_stream);
                             if (flags & GPUAR_STATUS_BAD_PACKET)
                                 throw std::runtime_error("Incorrect file format (malformed packet between file offsets " + std::to_string(chunk.begin) +
                                                          " and " + std::to_string(chunk.end) + ")");
@@ -1057,6 +1116,7 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                 std::rethrow_exception(lane_failure);
             }
             trace("decompress: lanes done");
+            trace("decompress: input windows unregistered while the job ran:", static_cast<double>(mapped.windowsTrimmed()));
             for (size_t g = 0; g < G; ++g)
                 trace(("decompress: device " + std::to_string(g) + " decoded " + std::to_string(device_bytes[g].load()) + " bytes in " +
                        std::to_string(device_chunks[g].load()) + " chunks").c_str());

@@ -171,6 +171,19 @@ def test_gpu_cli_file_over_4gib(tmp_path):
     want_tail = O.best().encode_stream(islands[n - 4321 - 8192]).tobytes()
     assert blob[-len(want_tail):] == want_tail
     assert len(blob) > 20 + (npk - 8) * 210
+    # The mapped input is registered for DMA in 256 MiB windows; windows nobody copies from any more are unregistered
+    # once more than GPUAR_MAX_WINDOWS (default 16 = 4 GiB) are registered, so the pinned footprint does not grow with
+    # the file.  With a cap of two the 17 windows of this file are recycled again and again: same bytes out.
+    import re
+    gip2 = tmp_path / "big2.gip"
+    env = dict(os.environ, GPUAR_MAX_WINDOWS="2", GPUAR_TRACE="1")
+    r = subprocess.run([CLI, "c", f"--in={src}", f"--out={gip2}"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "every window registered" in r.stderr
+    trimmed = float(re.search(r"input windows unregistered while the job ran: ([0-9.]+)", r.stderr).group(1))
+    assert trimmed >= 12, r.stderr[-2000:]
+    assert gip2.read_bytes() == blob
+    gip2.unlink()
     del blob
     r = run("d", f"--in={gip}", f"--out={back}")
     assert r.returncode == 0, r.stderr
