@@ -1201,14 +1201,20 @@ scan_offsets_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, uint6
     }
 }
 
-// One wavefront moves one packet: 16 B per lane per step, destination-aligned
-// stores, source read through byte-exact unaligned loads.
-__global__ void __launch_bounds__(256)
+// One workgroup of 256 threads moves one packet, 16 bytes per lane and round (three rounds for a packet of uniform data,
+// two for text): destination-aligned stores, the source read through byte-exact unaligned loads.  Rounds 1-3 gave
+// every packet ONE wavefront that looped over it (four packets per workgroup): 3.43 ms for the 8.66 GB stream of the
+// bench workload, 5.0 TB/s read + write; with a workgroup per packet (measured, uniform / text 8 GiB: 192 threads 3.37 /
+// 2.14 ms, 256: 3.00 / 2.03, 320: 2.90 / 2.15, 384: 2.93 / 2.17, 448: 3.03 / 2.25, 576 = one quad per thread: 3.26 /
+// 2.70) it is 5.76 TB/s = 72 % of the datasheet's 8 TB/s, 93 % of what a plain copy reaches on this part (6.18 TB/s).
+#ifndef GPUAR_GATHER_THREADS
+#define GPUAR_GATHER_THREADS 256
+#endif
+constexpr uint32_t kGatherThreads = GPUAR_GATHER_THREADS;
+__global__ void __launch_bounds__(kGatherThreads)
 gather_kernel(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ offsets, uint32_t n_packets,
               uint8_t *__restrict__ stream) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const size_t packet = static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
-    if (packet >= n_packets) return;
+    const size_t packet = blockIdx.x;
     const uint8_t *src = slots + packet * kSlot;
     const uint64_t off = offsets[packet];
     const uint32_t len = static_cast<uint32_t>(offsets[packet + 1] - off);
@@ -1216,15 +1222,17 @@ gather_kernel(const uint8_t *__restrict__ slots, const uint64_t *__restrict__ of
     // head: bytes up to the first 16-byte boundary of dst
     uint32_t head = static_cast<uint32_t>((16u - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
     if (head > len) head = len;
-    if (lane < head) dst[lane] = src[lane];
     const uint32_t body = (len - head) & ~15u;
-    for (uint32_t at = lane * 16u; at < body; at += 64u * 16u) {
+    const uint32_t tail = len - head - body;
+    for (uint32_t at = threadIdx.x * 16u; at < body; at += kGatherThreads * 16u) {
         uint4 v;
         __builtin_memcpy(&v, src + head + at, 16);
         *reinterpret_cast<uint4 *>(dst + head + at) = v;
     }
-    const uint32_t tail = len - head - body;
-    if (lane < tail) dst[head + body + lane] = src[head + body + lane];
+    // the ragged ends: 32 lanes of the last wavefront
+    const uint32_t spare = threadIdx.x - (kGatherThreads - 32u);
+    if (spare < head) dst[spare] = src[spare];
+    else if (spare >= 16u && spare - 16u < tail) dst[head + body + spare - 16u] = src[head + body + spare - 16u];
 }
 
 // ---------------------------------------------------------------------------
@@ -1396,7 +1404,7 @@ int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_strea
     gpuar::scan_tile_sums_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, tile_prefix);
     gpuar::scan_tile_prefix_kernel<<<1, gpuar::kScanThreads, 0, s>>>(static_cast<uint32_t>(tiles), tile_prefix);
     gpuar::scan_offsets_kernel<<<static_cast<uint32_t>(tiles), gpuar::kScanThreads, 0, s>>>(d_slots, np, d_offsets, tile_prefix);
-    gpuar::gather_kernel<<<static_cast<uint32_t>((n_packets + 3) / 4), 256, 0, s>>>(d_slots, d_offsets, np, d_stream);
+    gpuar::gather_kernel<<<np, gpuar::kGatherThreads, 0, s>>>(d_slots, d_offsets, np, d_stream);
     return check_launch();
 }
 
