@@ -682,6 +682,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
             "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
             "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
+            GPUAR_STREAM_EARLY
 
 #define GPUAR_MID_WRITEBACK \
             "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
@@ -782,10 +783,16 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // keeps the ring filled).  The ds_read of
 // `ahead` is never waited for by itself: it is older than the record read of this very symbol, whose
 // s_waitcnt lgkmcnt(1) (LDS operations complete in order) comes long before the next refill reads `ahead`.
+// The window's borrow is formed EARLY (GPUAR_STREAM_EARLY: the tail of the first shadow, into a scalar pair of its own) and
+// only read here: a lane mask that a vector instruction has just written is not there yet for the scalar unit, and
+// s_and_saveexec right behind its v_sub_co (rounds 2-3) stalled the wavefront for 12 cycles per symbol.
+#define GPUAR_STREAM_EARLY \
+            "v_sub_co_u32 %[rem], %[sb], %[rem], %[n]\n\t" /* borrow: w0 ran out */ \
+            "v_and_b32 %[rem], 31, %[rem]\n\t"
+#define GPUAR_STREAM_HEAD \
+            "s_and_saveexec_b64 %[sx], %[sb]\n\t" /* (no branch around the region: some lane refills on almost every symbol) */
 #define GPUAR_STREAM_TEXT \
-            "v_sub_co_u32 %[rem], vcc, %[rem], %[n]\n\t" /* borrow: w0 ran out */ \
-            "v_and_b32 %[rem], 31, %[rem]\n\t" \
-            "s_and_saveexec_b64 %[sx], vcc\n\t" /* (no branch around the region: some lane refills on almost every symbol) */ \
+            GPUAR_STREAM_HEAD \
             "v_mov_b32 %[w0], %[w1]\n\t" \
             "v_perm_b32 %[w1], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
             "v_and_or_b32 %[t0], %[next], %[kf00], %[ring]\n\t" /* ring + 256 * (dword index mod 16) */ \
@@ -804,7 +811,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 
 #define GPUAR_STEP_OPERANDS_COMMON \
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
-              [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), [sb] "=&s"(sb), \
               [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
               [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [oaddr] "+v"(oaddr), \
               [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), [n] "+v"(nbits), \
@@ -813,7 +820,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 
 #define GPUAR_STEP_LOCALS \
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
-        unsigned long long m0, m1, ma, mc, mj, sx;
+        unsigned long long m0, m1, ma, mc, mj, sx, sb;
 
 #define GPUAR_DECODE_SYMBOL(K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD, J) \
     { \
@@ -932,14 +939,14 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         uint32_t t_, t2_;                                                                                            \
         unsigned long long sx_;                                                                                      \
         asm volatile(                                                                                                \
+            "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
+            "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
+            "v_cmp_gt_u32 vcc, 49, %[t]\n\t" /* (first: the scalar unit reads this mask five instructions later) */  \
             "s_waitcnt vmcnt(0)\n\t"                                                                                 \
             "ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                                    \
             "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t"                                          \
             "global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[off]\n\t"                                \
             "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[off]+16\n\t"                             \
-            "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
-            "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
-            "v_cmp_gt_u32 vcc, 49, %[t]\n\t"                                                                         \
             "s_and_saveexec_b64 %[sx], vcc\n\t"                                                                      \
             "v_min_u32 %[t], %[fill], %[lastp]\n\t"                                                                  \
             "global_load_dwordx4 v[220:223], %[t], %[base]\n\t"                                                      \

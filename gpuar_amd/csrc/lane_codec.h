@@ -609,24 +609,34 @@ struct CarryCoderLane {
     // take_top() + leave(); shared by the throughput kernel's coder and the latency kernel's sink)
 #if defined(__HIP_DEVICE_COMPILE__)
     GPUAR_LANE void shift_and_store(uint32_t n) {
-        {
-            const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
-            wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
-        }
-        held += n;
         // The store region, predicated by hand, NO branch around it (some lane has a dword leaving on almost every symbol):
         // the common line of leave() -- cache + carry goes to memory, the leaving dword becomes the cache.  Lanes for which
         // that is not the whole story (a leaving dword of 32 ones, or such dwords waiting) are named in `rare` and put
         // right behind the region, from what the region left: `sent` (what was stored), `word`, `over`.
-        // (every shift below takes `held` itself as its count: the hardware looks at the low five bits only, and
-        // held - 16 = held + 16 (mod 32) -- so the device keeps `held` 16 too high, see open())
-        const unsigned long long full = __builtin_amdgcn_ballot_w64(held >= 48u);
-        unsigned long long saved;
+        // (Every shift in the region takes `held` itself as its count: the hardware looks at the low five bits only, and
+        // held - 16 = held + 16 (mod 32) -- so the device keeps `held` 16 too high, see open().)
+        // A lane mask that a vector instruction has just written is not yet there for the scalar unit: s_and_saveexec right
+        // behind its v_cmp stalls the wavefront (the decoder's stream window lost 12 cycles per symbol that way,
+        // profiles/r04_decode_cost_attribution.txt).  So the compare comes FIRST, the window's 64-bit shift behind it, the
+        // region last; and the compare that finds the rare lanes sits inside the region, ten instructions before the
+        // scalar test of its result.  One compare finds both kinds: `key` is 0xFFFFFFFF (word >= key: 32 ones) or, while
+        // dwords wait, 0 (always).
+        unsigned long long full, saved, rare;
         uint32_t word, over, sent, t_mask, t_addr, t_swapped;
+        asm volatile(
+            "v_add_u32 %[held], %[held], %[n]\n\t"
+            "v_cmp_le_u32 %[m], 48, %[held]"
+            : [held] "+v"(held), [m] "=&s"(full)
+            : [n] "v"(n));
+        {
+            const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
+            wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        }
         asm volatile(
             "s_and_saveexec_b64 %[sx], %[m]\n\t"
             "v_alignbit_b32 %[word], %[wh], %[wl], %[held]\n\t"
             "v_lshrrev_b32 %[over], %[held], %[wh]\n\t"
+            "v_cmp_ge_u32 %[rare], %[word], %[key]\n\t"                  /* (bits of lanes that do not store stay 0) */
             "v_bfm_b32 %[tm], %[held], 0\n\t"
             "v_add_u32 %[sent], %[cache], %[over]\n\t"
             "v_min_u32 %[ta], %[at], %[last]\n\t"
@@ -639,13 +649,12 @@ struct CarryCoderLane {
             "v_add_u32 %[held], -32, %[held]\n\t"
             "s_or_b64 exec, exec, %[sx]"
             : [wl] "+v"(wl), [wh] "+v"(wh), [at] "+v"(at), [held] "+v"(held), [cache] "+v"(cache), [word] "=&v"(word),
-              [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped), [sx] "=&s"(saved)
-            : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base)
+              [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped), [sx] "=&s"(saved),
+              [rare] "=&s"(rare)
+            : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base), [key] "v"(key)
             : "memory");
 #ifndef GPUAR_CARRY_NO_RARE        // (timing experiments only: without the rare path the kernel is WRONG for dwords of 32 ones)
-        // one compare finds both kinds: `key` is 0xFFFFFFFF (word >= key: 32 ones) or, while dwords wait, 0 (always)
-        const unsigned long long rare = __builtin_amdgcn_ballot_w64(word >= key) & full;
-        if (__builtin_expect(rare != 0ull, 0)) {              // wave-uniform (a lane mask from a ballot)
+        if (__builtin_expect(rare != 0ull, 0)) {              // wave-uniform (a lane mask in scalar registers)
             const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             if ((rare >> lane) & 1ull) {
                 if (word == 0xFFFFFFFFu && over == 0u) {      // not decided yet: it waits, and so does the cache again
