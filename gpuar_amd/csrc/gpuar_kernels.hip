@@ -378,8 +378,20 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
                 ahead = ahead > kPacket - kPhase ? kPacket - kPhase : ahead;
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[ahead + j];
+#ifdef GPUAR_CODER_OWED_BITS
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
+#else
+                // the step in its three pieces (lane_codec.h): the NEXT symbol's two divisions sit between this symbol's
+                // "who stores?" compare and the store region that reads the answer
+                CarryCoderLane::Ahead next = coder.ahead(cums[0], rc[0]);
+#pragma unroll
+                for (uint32_t j = 0; j < kPhase; ++j) {
+                    const CarryCoderLane::Narrowed now = coder.narrow(next);
+                    if (j + 1u < kPhase) next = coder.ahead(cums[j + 1u], rc[j + 1u]);
+                    coder.settle(now);
+                }
+#endif
             } else {
 #pragma unroll 1
                 for (uint32_t j = 0; j < kPhase; ++j) {

@@ -608,7 +608,8 @@ struct CarryCoderLane {
     // w <<= n, held += n, and the dword on top of the held bits leaves once there are 32 (the GPU's version of
     // take_top() + leave(); shared by the throughput kernel's coder and the latency kernel's sink)
 #if defined(__HIP_DEVICE_COMPILE__)
-    GPUAR_LANE void shift_and_store(uint32_t n) {
+    // `full`: the lanes with 32 bits held once this symbol's n are in (settled_mask(): formed well before this is called)
+    GPUAR_LANE void shift_and_store(uint32_t n, unsigned long long full) {
         // The store region, predicated by hand, NO branch around it (some lane has a dword leaving on almost every symbol):
         // the common line of leave() -- cache + carry goes to memory, the leaving dword becomes the cache.  Lanes for which
         // that is not the whole story (a leaving dword of 32 ones, or such dwords waiting) are named in `rare` and put
@@ -621,13 +622,8 @@ struct CarryCoderLane {
         // region last; and the compare that finds the rare lanes sits inside the region, ten instructions before the
         // scalar test of its result.  One compare finds both kinds: `key` is 0xFFFFFFFF (word >= key: 32 ones) or, while
         // dwords wait, 0 (always).
-        unsigned long long full, saved, rare;
+        unsigned long long saved, rare;
         uint32_t word, over, sent, t_mask, t_addr, t_swapped;
-        asm volatile(
-            "v_add_u32 %[held], %[held], %[n]\n\t"
-            "v_cmp_le_u32 %[m], 48, %[held]"
-            : [held] "+v"(held), [m] "=&s"(full)
-            : [n] "v"(n));
         {
             const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
             wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
@@ -671,10 +667,42 @@ struct CarryCoderLane {
     }
 #endif
 
-    GPUAR_LANE void step(uint32_t cums, Recip rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // held += n, and which lanes then hold a whole dword -- asked HERE, several instructions before the store region's
+    // s_and_saveexec reads the answer (see shift_and_store)
+    GPUAR_LANE unsigned long long settled_mask(uint32_t n) {
+        unsigned long long full;
+        asm volatile("v_add_u32 %[held], %[held], %[n]\n\t"
+                     "v_cmp_le_u32 %[m], 48, %[held]"
+                     : [held] "+v"(held), [m] "=&s"(full)
+                     : [n] "v"(n));
+        return full;
+    }
+#endif
+
+    // The step in three pieces, so that a caller with the next symbol's sums at hand (encode_kernel's unrolled phase) can put
+    // that symbol's two divisions between this symbol's compare and its store region:
+    //     ahead(cums, rc)  the two bounds of the symbol's interval (needs `range` as the symbol before it left it)
+    //     narrow(a)        w += dn, the renormalisation count, range', held -- and the mask of the lanes that will store
+    //     settle(r)        w <<= n, the store region, the rare path
+    // step() is the three in a row.
+    struct Ahead {
+        uint32_t dn, wd;
+    };
+    struct Narrowed {
+        uint32_t n;
+        unsigned long long full;
+    };
+    GPUAR_LANE Ahead ahead(uint32_t cums, Recip rc) const {
+        // (Plain code on purpose.  Pinned as a volatile statement between the compare of the symbol before and that symbol's
+        // store region -- seven more instructions for the scalar unit to wait behind -- the phase ran 24 % SLOWER (18.5 -> 23.0 ms
+        // on 8 GiB): the compiler then has to have the sums and the reciprocals ready earlier than it likes.)
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
-        const uint32_t wd = up - dn;                          // new hi - new lo + 1
+        return {dn, up - dn};                                 // up - dn = new hi - new lo + 1
+    }
+    GPUAR_LANE Narrowed narrow(Ahead a) {
+        const uint32_t dn = a.dn, wd = a.wd;
 #if defined(__HIP_DEVICE_COMPILE__)
         // w += dn; n = renorm_count(w[15:0], wd) -- one statement: the xor lands in HALF a register (SDWA) and may be read
         // by the second instruction behind it at the earliest, so the order is fixed here
@@ -691,22 +719,33 @@ struct CarryCoderLane {
             : [wl] "+v"(wl), [wh] "+v"(wh), [kff] "+v"(kff), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
             : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u)
             : "vcc");
+        const unsigned long long full = settled_mask(n);
         range = wd << n;
-        shift_and_store(n);
+        return {n, full};
 #else
         const uint64_t sum = ((static_cast<uint64_t>(wh) << 32) | wl) + dn;
-        const uint32_t n = renorm_count(static_cast<uint32_t>(sum) & 0xFFFFu, wd);
-        const uint64_t w = sum << n;                          // 16 + held + n <= 64 (+ the carry bit above the held ones)
-        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        wl = static_cast<uint32_t>(sum), wh = static_cast<uint32_t>(sum >> 32);
+        const uint32_t n = renorm_count(wl & 0xFFFFu, wd);
         range = wd << n;
         held += n;
-        if (held >= 32u) {
+        return {n, held >= 32u ? 1ull : 0ull};
+#endif
+    }
+    GPUAR_LANE void settle(Narrowed r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        shift_and_store(r.n, r.full);
+#else
+        const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << r.n;     // 16 + held <= 64 (+ the carry bit above the held ones)
+        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        if (r.full) {
             uint32_t over;
             const uint32_t word = take_top(over);
             leave(word, over);
         }
 #endif
     }
+
+    GPUAR_LANE void step(uint32_t cums, Recip rc) { settle(narrow(ahead(cums, rc))); }
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t key = 0xFFFFFFFFu;       // what a leaving dword is compared with to find the rare cases: 0 while nff != 0
 #endif
@@ -800,7 +839,8 @@ struct CarrySinkLane : CarryCoderLane {
             : [wl] "+v"(wl), [wh] "+v"(wh), [n] "=&v"(n)
             : [p] "v"(packed)
             : "vcc");
-        shift_and_store(n);
+        const unsigned long long full = settled_mask(n);
+        shift_and_store(n, full);
 #else
         const uint32_t n = packed >> 16;
         const uint64_t w = ((((static_cast<uint64_t>(wh) << 32) | wl) + (packed & 0xFFFFu)) << n);
