@@ -670,12 +670,15 @@ struct CarryCoderLane {
 #if defined(__HIP_DEVICE_COMPILE__)
     // held += n, and which lanes then hold a whole dword -- asked HERE, several instructions before the store region's
     // s_and_saveexec reads the answer (see shift_and_store)
-    GPUAR_LANE unsigned long long settled_mask(uint32_t n) {
+    // (`wd`: the new width; range' = wd << n is formed here as well, behind the compare: one more instruction between the
+    // compare and the region)
+    GPUAR_LANE unsigned long long settled_mask(uint32_t n, uint32_t wd) {
         unsigned long long full;
         asm volatile("v_add_u32 %[held], %[held], %[n]\n\t"
-                     "v_cmp_le_u32 %[m], 48, %[held]"
-                     : [held] "+v"(held), [m] "=&s"(full)
-                     : [n] "v"(n));
+                     "v_cmp_le_u32 %[m], 48, %[held]\n\t"
+                     "v_lshlrev_b32 %[rng], %[n], %[wd]"
+                     : [held] "+v"(held), [m] "=&s"(full), [rng] "=v"(range)
+                     : [n] "v"(n), [wd] "v"(wd));
         return full;
     }
 #endif
@@ -695,8 +698,9 @@ struct CarryCoderLane {
     };
     GPUAR_LANE Ahead ahead(uint32_t cums, Recip rc) const {
         // (Plain code on purpose.  Pinned as a volatile statement between the compare of the symbol before and that symbol's
-        // store region -- seven more instructions for the scalar unit to wait behind -- the phase ran 24 % SLOWER (18.5 -> 23.0 ms
-        // on 8 GiB): the compiler then has to have the sums and the reciprocals ready earlier than it likes.)
+        // store region -- more instructions for the scalar unit to wait behind -- the phase ran 24 % SLOWER (18.4 -> 23.0 ms on
+        // 8 GiB), and so did pinning just the two products there: anything that touches the NEXT symbol's sums in front of this
+        // symbol's store region costs more than the stall it was meant to fill.)
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
         return {dn, up - dn};                                 // up - dn = new hi - new lo + 1
@@ -719,8 +723,7 @@ struct CarryCoderLane {
             : [wl] "+v"(wl), [wh] "+v"(wh), [kff] "+v"(kff), [h] "=&v"(h), [t2] "=&v"(t2), [c] "=&v"(c), [t] "=&v"(t), [n] "=&v"(n)
             : [dn] "v"(dn), [wd] "v"(wd), [km] "s"(0xFFFF8000u)
             : "vcc");
-        const unsigned long long full = settled_mask(n);
-        range = wd << n;
+        const unsigned long long full = settled_mask(n, wd);
         return {n, full};
 #else
         const uint64_t sum = ((static_cast<uint64_t>(wh) << 32) | wl) + dn;
@@ -839,7 +842,7 @@ struct CarrySinkLane : CarryCoderLane {
             : [wl] "+v"(wl), [wh] "+v"(wh), [n] "=&v"(n)
             : [p] "v"(packed)
             : "vcc");
-        const unsigned long long full = settled_mask(n);
+        const unsigned long long full = settled_mask(n, 0u);     // (the sink has no range of its own: the shift of 0 is dead weight of one instruction)
         shift_and_store(n, full);
 #else
         const uint32_t n = packed >> 16;
