@@ -447,6 +447,65 @@ def test_round_trips_over_ten_source_models(H, oracle, seed, encode_mode):
         assert np.array_equal(got[off[p]:off[p + 1]], want), f"packet {p} (source model {p % 10})"
 
 
+@pytest.fixture(scope="module")
+def small_slot_lib():
+    """libgpuar_hip.so built with 1024-byte slots (tests/_build/): ordinary data then drives packets past the end of
+    their slots, which no input can do with the real 8704 bytes -- the only way to run the coders' end-of-slot paths
+    (the clamped store region, GPUAR_STATUS_SLOT_OVERFLOW) on the device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libgpuar_hip_slot1024.so")
+    srcs = [os.path.join(root, "gpuar_amd", "csrc", f) for f in ("gpuar_kernels.hip", "lane_codec.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+        host_o = os.path.join(root, "build", "host_codec.o")
+        if not os.path.exists(host_o):
+            subprocess.check_call(["make", "-C", os.path.join(root, "gpuar_amd", "csrc"), host_o])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{root}/include",
+                               "-Wno-unused-function", "-mllvm", "-phi-node-folding-threshold=64", "-mllvm",
+                               "-two-entry-phi-node-folding-threshold=64", "-DGPUAR_SLOT_BYTES=1024u", "-shared", "-o", so,
+                               host_o, srcs[0]], cwd=os.path.dirname(srcs[0]))
+    lib = C.CDLL(so)
+    lib.gpuar_hip_encode_mode.restype = C.c_int
+    lib.gpuar_hip_encode_mode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["throughput", "latency"])
+def test_slot_overflow_is_flagged_and_contained_on_the_device(small_slot_lib, oracle, mode):
+    """With 1024-byte slots: packets of random bytes (~8260 bytes of output) outgrow their slots, a packet of zeros
+    (210 bytes) between them fits.  The launch reports GPUAR_STATUS_SLOT_OVERFLOW in its own status word, nothing is
+    written beyond the slot array or into a neighbour's slot, an overflowed slot's header says clen = slot size and
+    ulen, what it holds up to its last two dwords is the true prefix of the packet, and the packet that fits is exact."""
+    slot = 1024
+    rng = np.random.default_rng(5)
+    groups = 3                                              # 192 packets: three workgroups, every lane of the first busy
+    data = rng.integers(0, 256, groups * 64 * 8192, dtype=np.uint8)
+    fits = [1, 64, 130]                                     # these packets are zeros
+    for p in fits:
+        data[p * 8192:(p + 1) * 8192] = 0
+    npk = groups * 64
+    d_in = torch.from_numpy(data).cuda()
+    guard = 4096
+    d_slots = torch.full((npk * slot + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = small_slot_lib.gpuar_hip_encode_mode(d_in.data_ptr(), data.size, d_slots.data_ptr(), word.data_ptr(), None, mode)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(word.item()) & 1, (rc, int(word.item()))
+    got = d_slots.cpu().numpy()
+    assert (got[npk * slot:] == 0xA5).all()                 # nothing beyond the last slot
+    zero_pkt = np.frombuffer(oracle.encode_packet(bytes(8192)), dtype=np.uint8)
+    for p in fits:
+        assert np.array_equal(got[p * slot:p * slot + zero_pkt.size], zero_pkt), p
+        assert (got[p * slot + zero_pkt.size + 3:(p + 1) * slot] == 0xA5).all(), p      # (the tail store may round up to a dword)
+    for p in (0, 2, 63, 65, 191):
+        want = np.frombuffer(oracle.encode_packet(data[p * 8192:(p + 1) * 8192].tobytes()), dtype=np.uint8)
+        s0 = got[p * slot:(p + 1) * slot]
+        assert int(s0[0]) | (int(s0[1]) << 8) == slot and int(s0[2]) | (int(s0[3]) << 8) == 8192, p
+        assert np.array_equal(s0[4:slot - 8], want[4:slot - 8]), p
+
+
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     """bench.py --gpus 2 through torch.distributed.run, both ranks on this box's one GPU (gloo control
     plane, GPUAR_OVERSUBSCRIBE_DEVICES=1): rank r codes bytes [r*B, (r+1)*B) of the stream, the JSON line
