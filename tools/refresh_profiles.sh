@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
-# Regenerates everything under profiles/ for a round tag (default r03), in three stages that each fit one gpurun call
+# Regenerates everything under profiles/ for a round tag (default r04), in three stages that each fit one gpurun call
 # (a call is limited to 20 minutes).  Run on the GPU box from the repository root:
-#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r03 uniform'
-#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r03 others'
-#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r03 bench'
+#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r04 uniform'
+#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r04 others'
+#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r04 bench'
 # then copy gpurun_out/profiles_<tag>/* into profiles/ (gpurun_out/ is what travels back).
 #   uniform : kernel trace + stats and all PMC passes on the bench workload (uniform 8 GiB): encode, compaction,
 #             decode (slots), decode (stream) -> <tag>_kernel_stats.csv, <tag>_rocprofv3_summary.txt, <tag>_traffic.json
@@ -11,7 +11,7 @@
 #   bench   : bench.py lines (uniform with CPU baseline, text, zipf), hardware probes, kernel time by stream kind and by
 #             occupancy, CLI wall times with the pipeline's own timeline
 set -u
-tag="${1:-r03}"
+tag="${1:-r04}"
 stage="${2:-uniform}"
 out="gpurun_out/profiles_$tag"
 mkdir -p "$out"
@@ -47,7 +47,7 @@ bench)
     for kind in text zipf; do
         timeout -k 10 200 python3 bench.py --kind "$kind" --seed 1 --gib-per-gpu 8 --no-cpu-baseline --no-small-config > "$out/${tag}_bench_$kind.json" 2>/dev/null
     done
-    for probe in valu_probe lds_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe; do
+    for probe in valu_probe lds_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe xlane_probe copy_probe; do
         [ -x "tools/$probe.bin" ] && timeout -k 10 200 "./tools/$probe.bin" > "$out/${tag}_$probe.txt" 2>&1
     done
     [ -x tools/io_probe.bin ] && timeout -k 10 200 ./tools/io_probe.bin /tmp 2 > "$out/${tag}_io_probe.txt" 2>&1
