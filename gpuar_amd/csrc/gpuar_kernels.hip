@@ -83,7 +83,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 //           lane_codec.h at TopModeler);
 //   CODER: two phases behind: owns the interval state and the bit sink, turns the
 //           sums into the packet bitstream;
-//   the fourth wavefront only meets the barriers.
+//   the fourth wavefront carries the coder's reciprocals from the table in memory into LDS, a phase ahead, and meets
+//           the barriers.
 // They meet in a three-slot LDS ring of kPhase symbols per slot (EncodeLds), one
 // s_barrier per phase.
 //
@@ -95,7 +96,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // stream (45 VALU + 13 LDS per symbol) as the bottleneck; cutting that stream
 // in two puts three wavefronts on every SIMD for the same LDS.  32 KiB tree +
 // 8 KiB of rings = 40 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
-// (plus the 4 idle ones that only meet the barriers, see encode_kernel).
+// (plus the 4 that only carry reciprocals and meet the barriers, see encode_kernel).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPhase = 8;
 // Issue priority of the three roles (s_setprio; a SIMD hosts one wavefront of each role, from different
@@ -118,7 +119,7 @@ constexpr int kPrioTop = GPUAR_PRIO_TOP, kPrioCoder = GPUAR_PRIO_CODER, kPrioLow
 // a time, so the ring has three slots.  The low modeler takes the symbols from the top one as well (as the row tags
 // the top modeler forms anyway, one u16 per lane and symbol), so only one wavefront of a group reads the input from memory.
 constexpr uint32_t kRingSlots = 3;
-struct EncodeLds {
+struct alignas(16) EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
     uint32_t sums[kRingSlots][kPhase][kLanes]; // 6 KiB: [slot][symbol][lane]
     uint16_t tags[2][kPhase][kLanes];          // 2 KiB: [phase parity][symbol][lane], the row tags (x << 7 | lane bits) of a
@@ -346,7 +347,20 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         __builtin_amdgcn_s_setprio(kPrioLow);
         run_low(lds, lane, len, len_min, n_phases);
     } else if (role == 3) {
-        for (uint32_t k = 0; k < n_phases + 2u; ++k) lds_barrier();
+        // The fourth wavefront carries the coder's reciprocals: the eight (multiplier, shift) pairs of a phase, 64 bytes of
+        // the table, go into one of two slots in the tree's unused 256th row one barrier before the coder reads them --
+        // lanes 0..15 load a dword each (asked for a whole interval ahead), write it, meet the barrier.
+        uint32_t *courier = reinterpret_cast<uint32_t *>(lds.tree + 255u * 128u);
+        const uint32_t *table = reinterpret_cast<const uint32_t *>(g_recip.r);
+        const uint32_t lane16 = lane & 15u;
+        uint32_t carried = table[lane16];                      // the pairs of phase 0
+        for (uint32_t k = 0; k < n_phases + 2u; ++k) {
+            // interval k: the coder will work on the symbols of phase k - 1 during interval k + 1 and reads slot (k + 1) & 1
+            if (lane < 16u) courier[((k + 1u) & 1u) * 16u + lane16] = carried;
+            const uint32_t next_phase = k < n_phases ? k : 0u;                     // (phase k's pairs, for interval k + 1's write)
+            carried = table[next_phase * 16u + lane16];
+            lds_barrier();
+        }
     } else {
         // ------------------------------- coder -------------------------------
         __builtin_amdgcn_s_setprio(kPrioCoder);
@@ -358,9 +372,6 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         CarryCoderLane coder;                // the lower bound as a 64-bit window, carries instead of owed bits (lane_codec.h)
 #endif
         coder.open(block_slots, lane * kSlot);
-        Recip rc_next[kPhase];                               // reciprocals are fetched one phase ahead
-#pragma unroll
-        for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[j];
         lds_barrier();                                       // phases 0 and 1: the modelers' first
         lds_barrier();
         uint32_t slot = 0;
@@ -372,12 +383,15 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in_ring[j * kLanes];
                 Recip rc[kPhase];
+                {
+                    // every lane reads the same 64 bytes: four broadcast reads, the pairs arrive as vector operands
+                    const uint4 *slot = reinterpret_cast<const uint4 *>(lds.tree + 255u * 128u + (k & 1u) * 64u);
 #pragma unroll
-                for (uint32_t j = 0; j < kPhase; ++j) rc[j] = rc_next[j];
-                uint32_t ahead = base + kPhase;                      // wave-uniform
-                ahead = ahead > kPacket - kPhase ? kPacket - kPhase : ahead;
-#pragma unroll
-                for (uint32_t j = 0; j < kPhase; ++j) rc_next[j] = g_recip.r[ahead + j];
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint4 v = slot[q];
+                        rc[2 * q] = {v.x, v.y}, rc[2 * q + 1] = {v.z, v.w};
+                    }
+                }
 #ifdef GPUAR_CODER_OWED_BITS
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
