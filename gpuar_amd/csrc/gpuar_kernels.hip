@@ -396,11 +396,11 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) coder.step(cums[j], rc[j]);
 #else
-                // the step in its three pieces (lane_codec.h): the compiler is free to put the NEXT symbol's two divisions
-                // between this symbol's "who stores?" compare and the store region that reads the answer.
+                // the step in its three pieces (lane_codec.h): the NEXT symbol's two divisions sit between this symbol's
+                // "who stores?" compare and the store region that reads the answer.
                 // (Measured and not kept: a wave-uniform choice per phase between this and a store region that does not
                 // clamp its address -- one vector instruction fewer per symbol while every lane has room for the phase's
-                // eight dwords -- made hipcc's schedule of the phase 20 % slower, 18.4 -> 22.3 ms on 8 GiB.)
+                // eight dwords: +1 % with the reciprocals coming through LDS, +20 % while they came by scalar loads.)
                 CarryCoderLane::Ahead next = coder.ahead(cums[0], rc[0]);
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {

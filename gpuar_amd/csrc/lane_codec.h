@@ -697,13 +697,28 @@ struct CarryCoderLane {
         unsigned long long full;
     };
     GPUAR_LANE Ahead ahead(uint32_t cums, Recip rc) const {
-        // (Plain code on purpose.  Pinned as a volatile statement between the compare of the symbol before and that symbol's
-        // store region -- more instructions for the scalar unit to wait behind -- the phase ran 24 % SLOWER (18.4 -> 23.0 ms on
-        // 8 GiB), and so did pinning just the two products there: anything that touches the NEXT symbol's sums in front of this
-        // symbol's store region costs more than the stall it was meant to fill.)
+        // A volatile statement on the GPU: it stays where the caller puts it -- between the "who stores?" compare of the symbol
+        // before and the store region that reads the compare's lane mask (seven more instructions for the scalar unit to wait
+        // behind; left to the compiler the divisions end up behind that region).  -0.5 %.  (While the coder still fetched its
+        // reciprocals by scalar loads this very statement cost 24 %, 18.4 -> 23.0 ms: it pulled the wait for the scalar load --
+        // which can only be lgkmcnt(0) -- in front of the phase's LDS reads.  The reciprocals now arrive through LDS.)
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t up, dn;
+        asm volatile("v_mul_u32_u24_sdwa %[up], %[c], %[r] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                     "v_mul_u32_u24_sdwa %[dn], %[c], %[r] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                     "v_mul_hi_u32 %[up], %[up], %[m]\n\t"
+                     "v_mul_hi_u32 %[dn], %[dn], %[m]\n\t"
+                     "v_lshrrev_b32 %[up], %[s], %[up]\n\t"
+                     "v_lshrrev_b32 %[dn], %[s], %[dn]\n\t"
+                     "v_sub_u32 %[up], %[up], %[dn]"
+                     : [up] "=&v"(up), [dn] "=&v"(dn)
+                     : [c] "v"(cums), [r] "v"(range), [m] "v"(rc.mul), [s] "v"(rc.shift));
+        return {dn, up};
+#else
         const uint32_t up = div_total(GPUAR_MUL24(cums >> 16, range), rc);
         const uint32_t dn = div_total(GPUAR_MUL24(cums & 0xFFFFu, range), rc);
         return {dn, up - dn};                                 // up - dn = new hi - new lo + 1
+#endif
     }
     GPUAR_LANE Narrowed narrow(Ahead a) {
         const uint32_t dn = a.dn, wd = a.wd;
