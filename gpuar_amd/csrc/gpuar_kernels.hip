@@ -444,6 +444,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 //     LOW      depth 0 (register), depth 7, the x == 255 term, added in place         15 + 4
 //     INTERVAL interval narrowing + renormalisation count -> one word per symbol      ~18 + 2   (lane_codec.h CarryIntervalLane)
 //     SINK     the window of held bits, carries, stores                               ~19 + 1   (CarrySinkLane)
+//     COURIER  (seventh wavefront) INTERVAL's reciprocals from the table into LDS, a phase ahead: no scalar load in a working role
 // Same integers as the throughput kernel (lane_codec.h is shared; tests/test_lane_emulation.py pins the cut coder
 // and a three-way tree against the oracle on the CPU), a different cut.  Rings: five slots of sums, four of input
 // bytes, two of interval words: 48 KiB of LDS per workgroup.  Every role meets n_phases + 5 barriers.
@@ -455,8 +456,9 @@ constexpr uint32_t kByteBufs = 4;            // the bytes of a phase are read by
 #ifndef GPUAR_SMALL_PHASE
 #define GPUAR_SMALL_PHASE 8
 #endif
-constexpr uint32_t kSmallPhase = GPUAR_SMALL_PHASE;   // symbols per phase: the roles meet at a barrier once per phase (must be 8 or 16)
-struct EncodeSmallLds {
+constexpr uint32_t kSmallPhase = GPUAR_SMALL_PHASE;   // symbols per phase: the roles meet at a barrier once per phase
+static_assert(kSmallPhase == 8, "the reciprocal courier's two slots (the tree's 256th row, 128 bytes) hold eight pairs each");
+struct alignas(16) EncodeSmallLds {
     uint8_t tree[kTreeRows * kLanes * 2];     // 32 KiB
     uint32_t sums[kSumSlots][kSmallPhase][kLanes];    // [slot][symbol][lane], cumLo | cumHi << 16 in the making
     uint32_t bytes[kByteBufs][kSmallPhase / 4][kLanes];    // the input bytes of a phase
@@ -555,7 +557,7 @@ __device__ __forceinline__ void small_follow(EncodeSmallLds &lds, uint32_t lane,
     for (uint32_t b = lag; b < kSmallLag; ++b) lds_barrier();
 }
 
-__global__ void __launch_bounds__(6 * kLanes)
+__global__ void __launch_bounds__(7 * kLanes)
 encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets, uint32_t *__restrict__ status) {
     __shared__ EncodeSmallLds lds;
     const size_t group = blockIdx.x;
@@ -580,6 +582,21 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         small_follow<PartialModeler<7, 5, 2, 0, false>>(lds, lane, len, len_min, n_phases, 2u);
     } else if (wave == 0u) {
         small_follow<DeepestModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
+    } else if (wave == 6u) {
+        // The seventh wavefront carries INTERVAL's reciprocals (as encode_kernel's fourth carries the coder's): the eight pairs
+        // of a phase go into one of two slots in the tree's unused 256th row one barrier before INTERVAL reads them, so that
+        // the wavefront that owns the interval chain never waits for a scalar load.
+        uint32_t *courier = reinterpret_cast<uint32_t *>(lds.tree + 255u * 128u);
+        const uint32_t *table = reinterpret_cast<const uint32_t *>(g_recip.r);
+        const uint32_t lane16 = lane & 15u;
+        uint32_t carried = table[lane16];
+        for (uint32_t t = 0; t < n_phases + kSmallLag; ++t) {
+            // interval t: INTERVAL works on phase t - 3 during interval t + 1 and reads slot (t - 3) & 1 = (t + 1) & 1
+            if (lane < 16u) courier[((t + 1u) & 1u) * 16u + lane16] = carried;
+            const uint32_t next_phase = t >= 2u && t - 2u < n_phases ? t - 2u : 0u;
+            carried = table[next_phase * 16u + lane16];
+            lds_barrier();
+        }
     } else if (wave == 2u) {
         CarryIntervalLane interval;
         interval.open();
@@ -592,8 +609,17 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
                 uint32_t cums[kSmallPhase];
 #pragma unroll
                 for (uint32_t j = 0; j < kSmallPhase; ++j) cums[j] = sums[j * kLanes];
+                Recip rc[kSmallPhase];
+                {
+                    const uint4 *slot = reinterpret_cast<const uint4 *>(lds.tree + 255u * 128u + (k & 1u) * 64u);
 #pragma unroll
-                for (uint32_t j = 0; j < kSmallPhase; ++j) out[j * kLanes] = interval.step(cums[j], g_recip.r[base + j]);
+                    for (uint32_t q = 0; q < kSmallPhase / 2; ++q) {
+                        const uint4 v = slot[q];
+                        rc[2 * q] = {v.x, v.y}, rc[2 * q + 1] = {v.z, v.w};
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kSmallPhase; ++j) out[j * kLanes] = interval.step(cums[j], rc[j]);
             } else {
 #pragma unroll 1
                 for (uint32_t j = 0; j < kSmallPhase; ++j) {
@@ -1401,7 +1427,7 @@ int gpuar_hip_encode_mode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots,
     // caller's `mode` is the only switch (no environment is read here).
     const bool latency = mode == GPUAR_MODE_LATENCY || (mode == GPUAR_MODE_AUTO && groups <= gpuar::kSmallGroups);
     if (latency) {
-        gpuar::encode_small_kernel<<<groups, 6 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+        gpuar::encode_small_kernel<<<groups, 7 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
             d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
         return check_launch();
     }
