@@ -50,8 +50,8 @@ KERNEL_SOURCES = ("gpuar_amd/csrc/gpuar_kernels.hip", "gpuar_amd/csrc/lane_codec
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "text"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
