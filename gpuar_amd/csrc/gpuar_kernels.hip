@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // ran at 108 GB/s; modeler + coder at 290 GB/s with the modeler's serial
 // stream (45 VALU + 13 LDS per symbol) as the bottleneck; cutting that stream
 // in two puts three wavefronts on every SIMD for the same LDS.  32 KiB tree +
-// 8 KiB of rings = 40 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
+// 7 KiB of rings = 39 KiB per workgroup -> exactly 4 workgroups = 12 working wavefronts/CU
 // (plus the 4 that only carry reciprocals and meet the barriers, see encode_kernel).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPhase = 8;
@@ -116,14 +116,16 @@ constexpr int kPrioTop = GPUAR_PRIO_TOP, kPrioCoder = GPUAR_PRIO_CODER, kPrioLow
 // The three roles work one phase apart -- the top modeler on the symbols of phase p, the low modeler on those of
 // p - 1, the coder on those of p - 2 -- and hand a phase on IN PLACE: the top modeler writes its part of
 // cumLo | cumHi << 16 per symbol, the low modeler adds its own, the coder reads the sum.  Three phases are alive at
-// a time, so the ring has three slots.  The low modeler takes the symbols from the top one as well (as the row tags
-// the top modeler forms anyway, one u16 per lane and symbol), so only one wavefront of a group reads the input from memory.
+// a time, so the ring has three slots.  The low modeler takes the symbols from the top one as well (the two input dwords
+// of a phase, one LDS instruction on either side; it forms its row tags itself, one SDWA shift per symbol -- a u16 tag per
+// symbol was eight LDS writes per phase in the top modeler's stream, the longest of the three, and eight reads in the low
+// one's), so only one wavefront of a group reads the input from memory.
 constexpr uint32_t kRingSlots = 3;
 struct alignas(16) EncodeLds {
     uint8_t tree[kTreeRows * kLanes * 2];      // 32 KiB: 255 rows x (64 lanes x u16), in-order layout
     uint32_t sums[kRingSlots][kPhase][kLanes]; // 6 KiB: [slot][symbol][lane]
-    uint16_t tags[2][kPhase][kLanes];          // 2 KiB: [phase parity][symbol][lane], the row tags (x << 7 | lane bits) of a
-                                               // phase's symbols, from the top modeler to the low one
+    uint32_t bytes[2][kPhase / 4][kLanes];     // 1 KiB: [phase parity][dword][lane], the input bytes of a phase's symbols as the
+                                               // top modeler read them, for the low one: ONE LDS write per phase and lane
 };
 __device__ __forceinline__ uint32_t next_slot(uint32_t slot) { return slot == kRingSlots - 1u ? 0u : slot + 1u; }
 
@@ -150,6 +152,17 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *p, size_t avail) 
     uint32_t w[4] = {0, 0, 0, 0};
     for (size_t b = 0; b < avail; ++b) w[b >> 2] |= static_cast<uint32_t>(p[b]) << (8u * (b & 3u));
     return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// byte kByte of `word`, seven bits up: the row tag of that symbol (lane_codec.h, InorderModel::tag) in one instruction
+__device__ __forceinline__ uint32_t byte_tag(uint32_t word, uint32_t kByte) {     // kByte: a constant once the caller's loop is unrolled
+    uint32_t t;
+    const uint32_t seven = 7u;
+    if (kByte == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(t) : "v"(seven), "v"(word));
+    if (kByte == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t) : "v"(seven), "v"(word));
+    if (kByte == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t) : "v"(seven), "v"(word));
+    if (kByte == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(t) : "v"(seven), "v"(word));
+    return t;
 }
 
 // The top modeler's wavefront.
@@ -204,15 +217,15 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
 #pragma unroll
             for (uint32_t ph = 0; ph < kChunkPhases; ++ph) {
                 uint32_t *out = &lds.sums[slot][0][lane];
-                uint16_t *tags = &lds.tags[ph & 1u][0][lane];            // k = kChunkPhases * q + ph, first term even
-                tags[0] = static_cast<uint16_t>(model.next_tag);         // the tag every step forms for its successor anyway
+                lds.bytes[ph & 1u][0][lane] = w[2 * ph];                 // k = kChunkPhases * q + ph, first term even
+                lds.bytes[ph & 1u][1][lane] = w[2 * ph + 1];
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {
                     const uint32_t i = ph * kPhase + j;                  // symbol index inside the chunk
-                    const uint32_t x = (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
-                    const uint32_t x_next = (w[(i + 1) >> 2] >> (8u * ((i + 1) & 3u))) & 0xFFu;
-                    out[j * kLanes] = model.step(x, 256u + q * kChunk + i, x_next);
-                    if (j + 1u < kPhase) tags[(j + 1u) * kLanes] = static_cast<uint16_t>(model.next_tag);
+                    // the successor's row tag straight out of its byte of the input word (one SDWA shift); this symbol's
+                    // own tag is the one the step before formed
+                    const uint32_t xn_tag = byte_tag(w[(i + 1) >> 2], (i + 1) & 3u);
+                    out[j * kLanes] = model.step_tag(model.next_tag, 256u + q * kChunk + i, xn_tag);
                 }
                 slot = next_slot(slot);
                 lds_barrier();
@@ -239,7 +252,8 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
                 else nxt = make_uint4(0, 0, 0, 0);
             }
             uint32_t *out = &lds.sums[slot][0][lane];
-            uint16_t *tags = &lds.tags[k & 1u][0][lane];
+            lds.bytes[k & 1u][0][lane] = words[0];
+            lds.bytes[k & 1u][1][lane] = words[1];
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q) {
                 uint32_t w = words[q], w_next = words[q + 1];
@@ -249,10 +263,8 @@ __device__ __forceinline__ void run_top(EncodeLds &lds, const uint8_t *in, uint3
                     const uint32_t x = w & 0xFFu;
                     w = (w >> 8) | (w_next << 24);            // next symbol now in the low byte
                     w_next >>= 8;
-                    *tags = static_cast<uint16_t>(model.next_tag);       // = tag(x) wherever i < len
                     if (i < len) *out = model.step(x, 256u + i, w & 0xFFu);
                     out += kLanes;
-                    tags += kLanes;
                 }
             }
             slot = next_slot(slot);
@@ -268,27 +280,39 @@ __device__ __forceinline__ void run_low(EncodeLds &lds, uint32_t lane, uint32_t 
     LowModeler<7> model;
     model.open(lds.tree, 2u * lane_column(lane), 0u);          // (the prefetch for symbol 0 is repeated below: harmless)
     lds_barrier();                                             // phase 0: the top modeler's first
-    uint32_t slot = 0;
-    for (uint32_t k = 0; k < n_phases; ++k) {                  // the symbols of phase k, during phase k + 1
+    uint32_t slot = 0, k = 0;
+    const uint32_t whole_phases = len_min / kPhase < n_phases ? len_min / kPhase : n_phases;    // (two loops: see the coder's)
+    for (; k < whole_phases; ++k) {                            // the symbols of phase k, during phase k + 1
         const uint32_t base = k * kPhase;
         uint32_t *io = &lds.sums[slot][0][lane];
-        const uint16_t *tags = &lds.tags[k & 1u][0][lane];
-        if (base + kPhase <= len_min) {
+        {
             uint32_t part[kPhase], tag[kPhase];
+            const uint32_t bytes[2] = {lds.bytes[k & 1u][0][lane], lds.bytes[k & 1u][1][lane]};
 #pragma unroll
-            for (uint32_t j = 0; j < kPhase; ++j) part[j] = io[j * kLanes], tag[j] = tags[j * kLanes];
+            for (uint32_t j = 0; j < kPhase; ++j) part[j] = io[j * kLanes], tag[j] = byte_tag(bytes[j >> 2], j & 3u);
             model.prime_tag(tag[0]);
+#ifdef GPUAR_EXP_NO_LOW          // (timing experiments only)
+            if (false)
+#endif
 #pragma unroll
             for (uint32_t j = 0; j < kPhase; ++j) {
                 if (j + 1u < kPhase) io[j * kLanes] = model.step_tag(tag[j], 256u + base + j, tag[j + 1u], part[j]);
                 else io[j * kLanes] = model.step_last_tag(tag[j], 256u + base + j, part[j]);
             }
-        } else {
+        }
+        slot = next_slot(slot);
+        lds_barrier();
+    }
+    for (; k < n_phases; ++k) {                                // the phases that hold a ragged tail
+        const uint32_t base = k * kPhase;
+        uint32_t *io = &lds.sums[slot][0][lane];
+        const uint32_t bytes[2] = {lds.bytes[k & 1u][0][lane], lds.bytes[k & 1u][1][lane]};
+        {
 #pragma unroll 1
             for (uint32_t j = 0; j < kPhase; ++j) {
                 const uint32_t i = base + j;
                 if (i < len) {
-                    const uint32_t t = tags[j * kLanes];
+                    const uint32_t t = model.tree.tag((bytes[j >> 2] >> (8u * (j & 3u))) & 0xFFu);
                     model.prime_tag(t);
                     io[j * kLanes] = model.step_last_tag(t, 256u + i, io[j * kLanes]);
                 }
@@ -374,11 +398,13 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         coder.open(block_slots, lane * kSlot);
         lds_barrier();                                       // phases 0 and 1: the modelers' first
         lds_barrier();
-        uint32_t slot = 0;
-        for (uint32_t k = 0; k < n_phases; ++k) {            // the symbols of phase k, during phase k + 2
-            const uint32_t base = k * kPhase;
+        uint32_t slot = 0, k = 0;
+        // Two loops, not one loop with two bodies: with both bodies in one loop the coder's eight state registers were copied
+        // to the whole-phase body's own set at the top of every phase and back at its end (16 of ~280 vector instructions).
+        const uint32_t whole_phases = len_min / kPhase < n_phases ? len_min / kPhase : n_phases;    // phases every lane owns completely
+        for (; k < whole_phases; ++k) {                      // the symbols of phase k, during phase k + 2
             const uint32_t *in_ring = &lds.sums[slot][0][lane];
-            if (base + kPhase <= len_min) {
+            {
                 uint32_t cums[kPhase];
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) cums[j] = in_ring[j * kLanes];
@@ -402,6 +428,9 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
                 // clamp its address -- one vector instruction fewer per symbol while every lane has room for the phase's
                 // eight dwords: +1 % with the reciprocals coming through LDS, +20 % while they came by scalar loads.)
                 CarryCoderLane::Ahead next = coder.ahead(cums[0], rc[0]);
+#ifdef GPUAR_EXP_NO_CODER        // (timing experiments only: what the kernel takes when the coder only meets its barriers)
+                if (false)
+#endif
 #pragma unroll
                 for (uint32_t j = 0; j < kPhase; ++j) {
                     const CarryCoderLane::Narrowed now = coder.narrow(next);
@@ -409,7 +438,14 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
                     coder.settle(now);
                 }
 #endif
-            } else {
+            }
+            slot = next_slot(slot);
+            lds_barrier();
+        }
+        for (; k < n_phases; ++k) {                          // the phases that hold a ragged tail
+            const uint32_t base = k * kPhase;
+            const uint32_t *in_ring = &lds.sums[slot][0][lane];
+            {
 #pragma unroll 1
                 for (uint32_t j = 0; j < kPhase; ++j) {
                     const uint32_t i = base + j;

@@ -39,6 +39,8 @@
 #define GPUAR_MAD24(a, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t r_; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "v"(b_), "v"(c_)); return r_; }((a), (b), (c)))
 // the same with the second factor uniform over the wavefront (a scalar register: no copy into a vector register)
 #define GPUAR_MAD24_VS(a, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t r_; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "s"(b_), "v"(c_)); return r_; }((a), (b), (c)))
+// c | (b where bit `bit` of a is set, else 0): the bit spread over the register (v_bfe_i32, width 1), then and-or; b uniform
+#define GPUAR_OR_WHERE_BIT(a, bit, b, c) ([](uint32_t a_, uint32_t b_, uint32_t c_) { uint32_t m_, r_; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"(a_), "n"(bit)); asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r_) : "v"(m_), "s"(b_), "v"(c_)); return r_; }((a), (b), (c)))
 // (a ^ 1) + b in one instruction; callers use only the low 16 bits
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // low 32 bits of (hi:lo) >> (s & 31)
@@ -61,6 +63,7 @@
 #define GPUAR_XOR1_ADD(a, b) ((((a) ^ 1u)) + (b))
 #define GPUAR_MAD24(a, b, c) ((a) * (b) + (c))
 #define GPUAR_MAD24_VS(a, b, c) ((a) * (b) + (c))
+#define GPUAR_OR_WHERE_BIT(a, bit, b, c) (((((a) >> (bit)) & 1u) ? (b) : 0u) | (c))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
@@ -233,17 +236,16 @@ struct InorderModel {
     uint8_t *table;      // first byte of the node table (same pointer in every lane of a wavefront)
     uint32_t lane_bits;  // this lane's byte offset inside a row (< 1 << kRowShift)
 
-    // x_tag = (x << kRowShift) | lane_bits, formed once per symbol; the node
-    // address is then ONE two-operand AND (a full-rate instruction) plus a
-    // compile-time offset the LDS instruction carries as an immediate.  The tag
-    // is made opaque: hipcc otherwise folds the OR into every level's AND as a
-    // three-operand v_bitop3_b32, which costs twice the issue time of v_and_b32
-    // (tools/valu_probe.hip: 4.6 against 2.3-2.7 cycles per SIMD slot).
-    GPUAR_LANE uint32_t tag(uint32_t x) const { return GPUAR_OPAQUE_V((x << kRowShift) | lane_bits); }
+    // x_tag = x << kRowShift, formed once per symbol (on the GPU straight out of the input word: one SDWA shift of its
+    // byte); the node address is then ONE and-or -- the tag's bits above the node's depth, this lane's column -- plus a
+    // compile-time offset the LDS instruction carries as an immediate.  (Rounds 1-3 kept the column inside the tag, for an
+    // address by a two-operand AND -- which needed an OR per symbol to put it there.  Issued between other wavefronts'
+    // instructions the two- and the three-operand forms cost the same)
+    GPUAR_LANE uint32_t tag(uint32_t x) const { return x << kRowShift; }
     GPUAR_LANE uint16_t *node(uint32_t x_tag, int k) const {
-        const uint32_t keep = (((0xFF00u >> k) & 0xFFu) << kRowShift) | ((1u << kRowShift) - 1u);
+        const uint32_t keep = ((0xFF00u >> k) & 0xFFu) << kRowShift;
         const uint32_t fixed = ((1u << (7 - k)) - 1u) << kRowShift;
-        return reinterpret_cast<uint16_t *>(table + (x_tag & keep) + fixed);
+        return reinterpret_cast<uint16_t *>(table + ((x_tag & keep) | lane_bits) + fixed);
     }
 };
 
@@ -308,8 +310,8 @@ struct PartialModeler {
     GPUAR_LANE uint32_t step(uint32_t x, uint32_t total, uint32_t x_next, uint32_t onto = 0) {
         return account<0, true>(paths_of_symbol(x), total, tree.tag(x_next), onto);
     }
-    // the same for a caller that has the row tags already (the low modeler of encode_kernel reads them from LDS, where the
-    // top modeler left them: no byte extraction, no shift-or, and the path bits come out of the tag by the same multiply-add)
+    // the same for a caller that has the row tags already (both modelers of encode_kernel form them straight out of the input
+    // words, one SDWA shift per symbol; the path bits come out of the tag by the same multiply-add)
     GPUAR_LANE uint32_t step_tag(uint32_t x_tag, uint32_t total, uint32_t xn_tag, uint32_t onto = 0) {
         return account<static_cast<int>(kRowShift), true>(paths_of_tag(x_tag), total, xn_tag, onto);
     }
@@ -321,7 +323,10 @@ struct PartialModeler {
     template <int kShift, bool kAhead>
     GPUAR_LANE uint32_t account(uint32_t z, uint32_t total, uint32_t xn, uint32_t onto) {
         uint32_t acc = onto;
-        if (kTail) acc = GPUAR_MAD24_VS((z >> (kShift + 8)) & 0x10000u, total, onto);  // x == 255: cumHi is the whole total
+        // x == 255: cumHi is the whole total.  Every OTHER term of cumHi is a count times a path bit of (x + 1) & 255 = 0 then,
+        // in this part and in the one `onto` came from: the high half is empty and the total can be OR-ed in (two instructions
+        // where shift, mask and multiply-add were three)
+        if (kTail) acc = GPUAR_OR_WHERE_BIT(z, kShift + 24, total << 16, onto);
         if (kHead >= 1) {
             const uint32_t pick0 = (z >> (kShift + 7)) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
@@ -622,7 +627,13 @@ struct CarryCoderLane {
         // region last; and the compare that finds the rare lanes sits inside the region, ten instructions before the
         // scalar test of its result.  One compare finds both kinds: `key` is 0xFFFFFFFF (word >= key: 32 ones) or, while
         // dwords wait, 0 (always).
-        unsigned long long saved, rare;
+        // The rare path is part of the same statement, behind a scalar branch: written in C++ behind the region, every
+        // symbol paid two register copies for it (what it changes -- nff, key -- came back in other registers, and the
+        // common path was the one that got the copies).  Lanes of `rare`:
+        //     32 ones and no carry: not decided yet -- the dword waits (++nff) and so does the cache again (at -= 4)
+        //     otherwise: decided -- the waiting dwords go out behind what was just stored (zeros behind a carry, else ones)
+        //     key = nff ? 0 : ~0
+        unsigned long long saved, rare, undecided;
         uint32_t word, over, sent, t_mask, t_addr, t_swapped;
         {
             const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
@@ -643,27 +654,42 @@ struct CarryCoderLane {
             "v_mov_b32 %[cache], %[word]\n\t"
             "v_add_u32 %[at], 4, %[at]\n\t"
             "v_add_u32 %[held], -32, %[held]\n\t"
-            "s_or_b64 exec, exec, %[sx]"
-            : [wl] "+v"(wl), [wh] "+v"(wh), [at] "+v"(at), [held] "+v"(held), [cache] "+v"(cache), [word] "=&v"(word),
-              [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped), [sx] "=&s"(saved),
-              [rare] "=&s"(rare)
-            : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base), [key] "v"(key)
-            : "memory");
+            "s_or_b64 exec, exec, %[sx]\n\t"
 #ifndef GPUAR_CARRY_NO_RARE        // (timing experiments only: without the rare path the kernel is WRONG for dwords of 32 ones)
-        if (__builtin_expect(rare != 0ull, 0)) {              // wave-uniform (a lane mask in scalar registers)
-            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            if ((rare >> lane) & 1ull) {
-                if (word == 0xFFFFFFFFu && over == 0u) {      // not decided yet: it waits, and so does the cache again
-                    at -= 4u;
-                    cache = sent;
-                    ++nff;
-                } else {                                      // decided: the waiting dwords go out behind what was just stored
-                    for (; nff; --nff) store_clamped(over ? 0u : 0xFFFFFFFFu);
-                }
-            }
-            key = nff ? 0u : 0xFFFFFFFFu;
-        }
+            "s_cmp_eq_u64 %[rare], 0\n\t"
+            "s_cbranch_scc1 .Lgpuar_common_%=\n\t"
+            "s_mov_b64 %[sx], exec\n\t"
+            "s_mov_b64 exec, %[rare]\n\t"
+            "v_cmp_eq_u32 vcc, -1, %[word]\n\t"
+            "v_cmp_eq_u32 %[und], 0, %[over]\n\t"
+            "v_cndmask_b32 %[tw], 0, -1, %[und]\n\t"                    /* what waiting dwords turn into: ones, zeros behind a carry */
+            "s_and_b64 %[und], %[und], vcc\n\t"
+            "s_and_b64 exec, %[rare], %[und]\n\t"                       /* -- undecided */
+            "v_add_u32 %[at], -4, %[at]\n\t"
+            "v_mov_b32 %[cache], %[sent]\n\t"
+            "v_add_u32 %[nff], 1, %[nff]\n\t"
+            "s_andn2_b64 exec, %[rare], %[und]\n\t"                     /* -- decided */
+            ".Lgpuar_fill_%=:\n\t"
+            "v_cmp_ne_u32 vcc, 0, %[nff]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz .Lgpuar_filled_%=\n\t"
+            "v_min_u32 %[ta], %[at], %[last]\n\t"
+            "global_store_dword %[ta], %[tw], %[base]\n\t"
+            "v_add_u32 %[at], 4, %[at]\n\t"
+            "v_add_u32 %[nff], -1, %[nff]\n\t"
+            "s_branch .Lgpuar_fill_%=\n\t"
+            ".Lgpuar_filled_%=:\n\t"
+            "s_mov_b64 exec, %[rare]\n\t"
+            "v_cmp_eq_u32 vcc, 0, %[nff]\n\t"
+            "v_cndmask_b32 %[key], 0, -1, vcc\n\t"
+            "s_mov_b64 exec, %[sx]\n\t"
+            ".Lgpuar_common_%=:"
 #endif
+            : [wl] "+v"(wl), [wh] "+v"(wh), [at] "+v"(at), [held] "+v"(held), [cache] "+v"(cache), [nff] "+v"(nff), [key] "+v"(key),
+              [word] "=&v"(word), [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped),
+              [sx] "=&s"(saved), [rare] "=&s"(rare), [und] "=&s"(undecided)
+            : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base)
+            : "memory", "vcc", "scc");
     }
 #endif
 

@@ -399,6 +399,38 @@ def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
     assert H.status() == 0
 
 
+def test_packets_that_keep_carrying_against_oracle(H, oracle, encode_mode):
+    """The coder's rare path (a leaving dword of 32 ones that has to wait for its carry, waiting dwords let go -- hand-written
+    behind a scalar branch in the store region, lane_codec.h) with every lane of a wavefront in a different state of it:
+    512 packets of two symbols either side of the interval's midpoint, few-symbol alphabets at every skew, and long
+    constant stretches, of ragged lengths; slot for slot against the oracle."""
+    rng = np.random.default_rng(2904)
+    npk = 512
+    data = np.zeros(npk * 8192, dtype=np.uint8)
+    for p in range(npk):
+        view = data[p * 8192:(p + 1) * 8192]
+        kind = p % 4
+        if kind == 0:
+            view[:] = np.where(rng.random(8192) < 0.5, 0x7F, 0x80).astype(np.uint8)
+        elif kind == 1:
+            view[:] = rng.choice(np.array([0x7F, 0x80, 0x00, 0xFF], dtype=np.uint8), 8192, p=[0.45, 0.45, 0.05, 0.05])
+        elif kind == 2:
+            view[:] = rng.choice(rng.integers(0, 256, int(rng.integers(2, 6))).astype(np.uint8), 8192)
+        else:
+            view[:] = np.repeat(rng.integers(0, 256, 8192 // 64).astype(np.uint8), 64)
+    n = npk * 8192 - 3001                               # the last packet is a short one
+    data = data[:n]
+    want, want_len, total = oracle_slots(oracle, data)
+    d_slots = H.encode(torch.from_numpy(data).cuda())
+    got = d_slots.cpu().numpy().reshape(npk, 8704)
+    got_len = got[:, 0].astype(np.int64) | (got[:, 1].astype(np.int64) << 8)
+    assert np.array_equal(want_len, got_len)
+    mask = np.arange(8704)[None, :] < want_len[:, None]
+    assert np.array_equal(got[mask], want[mask])
+    assert np.array_equal(H.decode(d_slots, npk).cpu().numpy()[:n], data)
+    assert H.status() == 0
+
+
 @pytest.mark.parametrize("seed", [7, 8])
 def test_round_trips_over_ten_source_models(H, oracle, seed, encode_mode):
     """4096 packets from ten source models -- uniform, few symbols, geometric, runs, ramps, midpoint pairs, a constant with
