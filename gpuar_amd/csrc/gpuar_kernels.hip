@@ -769,10 +769,15 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             (the head above reads only the lower half of lo : off) */ \
             "ds_add_u64 %[oaddr], v[204:205]\n\t"
 #define GPUAR_A_TAIL \
-            "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" /* register nodes += went left */ \
-            "v_addc_co_u32 %[t2], vcc, %[t2], 0, %[m1]\n\t" \
-            "v_cndmask_b32 %[h0], %[h0], %[t2], %[m0]\n\t" \
-            "v_cndmask_b32 %[h1], %[t2], %[h1], %[m0]\n\t" \
+         /* register nodes += went left: the root by the first decision's mask, of the two depth-1 nodes the one on the path by \
+            the second one's -- which of them it is, is settled between the two lane masks by the scalar unit (both were written \
+            a dozen instructions ago: no wait), so each node takes ONE add-with-carry (rounds 2-4: the chosen node's copy bumped, \
+            then two selects to put it back) */ \
+            "s_and_b64 %[sx], %[m0], %[m1]\n\t" \
+            "s_andn2_b64 %[mj], %[m1], %[m0]\n\t" \
+            "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" \
+            "v_addc_co_u32 %[h0], vcc, %[h0], 0, %[sx]\n\t" \
+            "v_addc_co_u32 %[h1], vcc, %[h1], 0, %[mj]\n\t" \
             GPUAR_STREAM_EARLY
 
 #define GPUAR_MID_WRITEBACK \

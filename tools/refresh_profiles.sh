@@ -47,7 +47,7 @@ bench)
     for kind in text zipf; do
         timeout -k 10 200 python3 bench.py --kind "$kind" --seed 1 --gib-per-gpu 8 --no-cpu-baseline --no-small-config > "$out/${tag}_bench_$kind.json" 2>/dev/null
     done
-    for probe in valu_probe lds_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe xlane_probe copy_probe; do
+    for probe in valu_probe lds_probe ldsbw_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe xlane_probe copy_probe; do
         [ -x "tools/$probe.bin" ] && timeout -k 10 200 "./tools/$probe.bin" > "$out/${tag}_$probe.txt" 2>&1
     done
     [ -x tools/io_probe.bin ] && timeout -k 10 200 ./tools/io_probe.bin /tmp 2 > "$out/${tag}_io_probe.txt" 2>&1
