@@ -54,6 +54,8 @@ def main(out_dir, tag, gib, kind="uniform"):
             res[k]["valu_busy_per_simd"] = avg("SQ_ACTIVE_INST_VALU") * 4.0 / (avg("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
         if d.get("SQ_INSTS_VALU"):
             res[k]["valu_insts_per_symbol_step"] = avg("SQ_INSTS_VALU") / symbol_steps
+        if d.get("SQ_INSTS_LDS"):
+            res[k]["lds_insts_per_symbol_step"] = avg("SQ_INSTS_LDS") / symbol_steps
     path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json" if kind == "uniform" and gib == 8 else f"{tag}_traffic_{kind}_{gib:g}gib.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res))
