@@ -761,12 +761,20 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
             "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
-#define GPUAR_A_SHADOW \
+#define GPUAR_A_SHADOW_PLAIN \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
-            64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left; v205: the grandchild's, if left there -- both \
-            formed by that symbol's step); no field can carry into its neighbour (counts stay below 2^14).  And the last \
-            instruction of the previous step's renormalisation: lo's top bit is cleared here, where it is needed next \
-            (the head above reads only the lower half of lo : off) */ \
+            64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left; v205: the grandchild's, if left there); no field \
+            can carry into its neighbour (counts stay below 2^14) */ \
+            "ds_add_u64 %[oaddr], v[204:205]\n\t"
+// The same with the previous symbol's low half ADDRESSED here -- one shift-add off the end of the chain into a shadow in which
+// the wavefront waits anyway (round 4: 26.64 -> 26.42 ms).  Measured and not kept: the filing of the previous symbol here
+// as well (its last decision's lane mask saved by s_mov_b64 and put back into vcc in front of the SDWA add-with-carry:
+// 26.83 ms) and, on top of that, the three selects that form the half's increments, from saved lane masks (27.89 ms): a
+// lane mask that travels vector -> scalar -> vector costs more than the instructions it moves off the chain; the filing
+// alone with the mask re-made here from the grandchild's increment (v_cmp_ne 0, v205 -- two instructions here for one on the
+// chain): +3 cycles, this shadow has no room left.
+#define GPUAR_A_SHADOW_DEFERRED \
+            "v_lshl_add_u32 %[oaddr], %[c6], 9, %[collow]\n\t" \
             "ds_add_u64 %[oaddr], v[204:205]\n\t"
 #define GPUAR_A_TAIL \
          /* register nodes += went left: the root by the first decision's mask, of the two depth-1 nodes the one on the path by \
@@ -780,17 +788,30 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_addc_co_u32 %[h1], vcc, %[h1], 0, %[mj]\n\t" \
             GPUAR_STREAM_EARLY
 
+// (the path after the record's first decision stays in `np` -- the two later ones go on in t3 -- so that the address of the
+// half that takes the increments is formed behind read #2, next to the LDS add that uses it, and not on the chain)
 #define GPUAR_MID_WRITEBACK \
-            "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[mc]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 10, %[collow]\n\t" \
+            "v_addc_co_u32 %[t3], %[mj], %[t3], %[t3], %[mc]\n\t" \
+            "v_lshl_add_u32 %[oaddr], %[t3], 10, %[collow]\n\t" \
             "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
          /* ---- the mid half takes its increments by one 64-bit LDS add in the shadow of read #2 */ \
+            "v_lshl_add_u32 %[am], %[np], 9, %[col]\n\t" /* where that half lives: its index is the path up to the record's first decision */ \
+            "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 v209, 0, %[t2], %[mc]\n\t" \
             "ds_add_u64 %[am], v[208:209]\n\t"
+#ifdef GPUAR_EXP_NO_WAIT1      /* (timing experiments only: garbage out) */
+#define GPUAR_WAIT1 ""
+#else
+#define GPUAR_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
+#endif
+#ifdef GPUAR_EXP_NO_WAIT2
+#define GPUAR_WAIT2 ""
+#else
+#define GPUAR_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
+#endif
 #define GPUAR_BC_MID \
-            "s_waitcnt lgkmcnt(1)\n\t" /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
+            GPUAR_WAIT1 /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: v200 = aR | bR << 16, v201 = cRR | cRL << 16 (right half), v202 = a | bL << 16, v203 = cLR | cLL << 16 (left half) */ \
             "v_mul_u32_u24_sdwa %[t0], v202, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
@@ -801,16 +822,19 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_sub_co_u32 %[t1], vcc, %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[ma]\n\t" \
-            "v_lshl_add_u32 %[am], %[np], 9, %[col]\n\t" /* where that half lives: its index is the path so far */ \
             "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[mc], %[R], %[t0]\n\t" \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_addc_co_u32 %[t3], %[mj], %[np], %[np], vcc\n\t" \
             GPUAR_MID_WRITEBACK
 
-#define GPUAR_BC_LOW \
-            "s_waitcnt lgkmcnt(1)\n\t" /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
+// OWN_ADDRESS: the address of the step's own low half, formed at once (GPUAR_LOW_ADDRESS_NOW: the last symbol of a loop body)
+// or left to the next step's first shadow (empty; GPUAR_A_SHADOW_DEFERRED)
+#define GPUAR_LOW_ADDRESS_NOW \
+            "v_lshl_add_u32 %[oaddr], %[c6], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */
+#define GPUAR_BC_LOW(OWN_ADDRESS) \
+            GPUAR_WAIT2 /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
          /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
                  Next to the walk (three decisions on the scaled remainder) the symbol's own COUNT is picked out of the half: \
                  under the chosen side there are `count` symbols (a or aR), `child` of them left of the child node, the \
@@ -826,14 +850,14 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_sub_co_u32 %[t1], vcc, %[R], %[pb]\n\t" \
             "v_sub_u32_sdwa %[ps], %[lbw], %[lbw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" /* count - child: right of the child node */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], %[lma]\n\t" \
-            "v_lshl_add_u32 %[oaddr], %[np], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */ \
+            "v_addc_co_u32 %[c6], %[mj], %[t3], %[t3], %[lma]\n\t" /* the path after six decisions (c6, c7: kept for the next step's shadow) */ \
+            OWN_ADDRESS \
          /* everything that hangs on the MIDDLE decision (vcc) comes first: the last decision's lane mask goes to vcc as well, \
-            because the instruction that files the symbol (the last one of the step) takes its carry from there */ \
+            because the instruction that files the symbol takes its carry from there */ \
             "v_cndmask_b32_sdwa %[t2], %[lcc], %[lcc], vcc" GPUAR_SDWA_HALVES \
             "v_cndmask_b32_sdwa %[ps], %[ps], %[lbw], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" /* symbols under the chosen grandchild node */ \
             "v_mul_u32_u24 %[pc], %[t2], %[rng]\n\t" \
-            "v_addc_co_u32 %[np], %[mj], %[np], %[np], vcc\n\t" \
+            "v_addc_co_u32 %[c7], %[mj], %[c6], %[c6], vcc\n\t" \
             "v_cndmask_b32 v204, 1, %[k64k1], vcc\n\t" /* the increments of the low half -> v204:v205 (added in the next step's shadow) */ \
             "v_cndmask_b32 %[ti], 1, %[k64k], vcc\n\t" \
             "v_sub_co_u32 %[t1], vcc, %[R], %[pc]\n\t" \
@@ -856,10 +880,9 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_ffbh_u32 %[e], %[t2]\n\t" /* lane_codec.h renorm_count: n = that count - 1 + [the bounds differ at that bit] */ \
             "v_xor_b32_sdwa %[kff], v217, %[h] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n\t"
 
-// The end of the step: the grandchild's increment sits between the SDWA write of kff and its reader; the LAST instruction
-// files the symbol: all eight complemented path bits = 2 * (the first seven) + the last decision's borrow, written
-// straight into byte J of the output word (SDWA dst_sel, the other bytes preserved) -- no shift-or per symbol
-// (GPUAR_FILE_SYMBOL, in front of the 64-bit shift).
+// The end of the step: the grandchild's increment sits between the SDWA write of kff and its reader; the last instruction
+// but one files the symbol: all eight complemented path bits = 2 * (the first seven) + the last decision's borrow, written
+// straight into byte J of the output word (SDWA dst_sel, the other bytes preserved) -- no shift-or per symbol.
 #define GPUAR_BC_LOW_END \
             "v_cndmask_b32 v205, 0, %[ti], vcc\n\t" \
             "v_lshlrev_b32 %[t2], %[e], %[kff]\n\t" \
@@ -869,7 +892,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // (not the statement's very last instruction: what reads the word behind the statement is the compiler's, and it does
 // not know that the word was written by halves)
 #define GPUAR_FILE_SYMBOL(J) \
-            "v_addc_co_u32_sdwa %[word], vcc, %[np], %[np], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_addc_co_u32_sdwa %[word], vcc, %[c7], %[c7], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
 // The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
 // w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
@@ -918,18 +941,36 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx, sb;
 
-#define GPUAR_DECODE_SYMBOL(K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD, J) \
+// TEXT: the step's instruction text (one of the three below); WORD: the output word the symbol is filed in
+#define GPUAR_DECODE_STATEMENT(TEXT, K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD) \
     { \
         GPUAR_STEP_LOCALS \
-        uint32_t lbw_, lcc_, ti_; \
+        uint32_t lbw_, lcc_, ti_, path7_; \
         unsigned long long lma_; \
-        asm volatile(GPUAR_A_HEAD GPUAR_A_SHADOW GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT \
+        asm volatile(TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1) \
+              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1), \
+              [c6] "+v"(path6), [c7] "=&v"(path7_) \
             : [tot] "s"((K_TOTAL)), [mul] "v"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
               [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [tbase] "s"((K_TOTAL0_M1)), [tj] "n"(POS) \
             : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
     }
+// The three kinds of step in a loop body of 32 symbols: all but the last leave the address of their low half to the next
+// step's first LDS shadow (the path after six decisions stays in a register of its own, `path6`), all but the first form it
+// there for their predecessor.
+#ifdef GPUAR_DEC_NO_DEFER      /* (A/B builds: every step forms its own address, as in rounds 2-4a) */
+#define GPUAR_STEP_FIRST(J) \
+    GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW(GPUAR_LOW_ADDRESS_NOW) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#define GPUAR_STEP_MIDDLE(J) GPUAR_STEP_FIRST(J)
+#define GPUAR_STEP_LAST(J) GPUAR_STEP_FIRST(J)
+#else
+#define GPUAR_STEP_FIRST(J) \
+    GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW() GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#define GPUAR_STEP_MIDDLE(J) \
+    GPUAR_A_HEAD GPUAR_A_SHADOW_DEFERRED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW() GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#define GPUAR_STEP_LAST(J) \
+    GPUAR_A_HEAD GPUAR_A_SHADOW_DEFERRED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW(GPUAR_LOW_ADDRESS_NOW) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#endif
 
 // LDS of a decoder workgroup (one wavefront): the 64 models and the 64 stream rings, 40 KiB -> four per CU.
 constexpr uint32_t kRingPieces = 4;                        // 16-byte pieces per lane: 64 bytes of stream
@@ -1077,20 +1118,20 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     uint32_t vzero;                                             // (a zero the compiler does not know: the loads' vector offset)
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 // Eight symbols (two output words) and the ring phase behind them; RUN (0..3) is the run's static position in the half block.
-#define GPUAR_DECODE_RUN8(RUN, WORD_A, WORD_B, SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
+#define GPUAR_DECODE_RUN8(RUN, FIRST_KIND, LAST_KIND, WORD_A, WORD_B, SET_AHEAD, TUPLE_LO, TUPLE_HI)                         \
         {                                                                                                            \
             const uint32_t j0 = 32u * half + 8u * (RUN); /* wave-uniform: first symbol of this run inside the block */ \
             const uint32_t total0 = 256u + i + j0;                                                                   \
             const uint32_t total0_m1 = 255u + i + j0; /* each step adds its position in the run as an inline constant */ \
-            /* every step writes its symbol into its own byte of the word (the step's last instruction) */          \
-            GPUAR_DECODE_SYMBOL(total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A, 0)                             \
-            GPUAR_DECODE_SYMBOL(total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A, 1)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A, 2)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A, 3)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B, 0)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B, 1)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B, 2)                        \
-            GPUAR_DECODE_SYMBOL(total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B, 3)                        \
+            /* every symbol goes into its own byte of its word */                                                    \
+            GPUAR_DECODE_STATEMENT(FIRST_KIND(0), total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A)              \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(1), total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A)  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(2), total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A)  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(3), total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A)  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(0), total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B)  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(1), total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B)  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(2), total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B)  \
+            GPUAR_DECODE_STATEMENT(LAST_KIND(3), total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B)          \
             /* ... and fetches the multipliers of the run after next: 8 * (RUN + 2) dwords behind the half block's first */ \
             GPUAR_RING_PHASE(32 * ((RUN) + 2), SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
         }
@@ -1104,10 +1145,14 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
         const uint32_t block_shift = 30u - static_cast<uint32_t>(__builtin_clz(256u + i));                           \
         _Pragma("unroll 1") for (uint32_t half = 0; half < 2u; ++half) {                                             \
             const uint32_t *mul_base = g_mul.m + i + 32u * half; /* wave-uniform: a scalar pair */                  \
-            GPUAR_DECODE_RUN8(0, w0, w1, 2, "v[240:243]", "v[244:247]")                                              \
-            GPUAR_DECODE_RUN8(1, w2, w3, 3, "v[248:251]", "v[252:255]")                                              \
-            GPUAR_DECODE_RUN8(2, w4, w5, 0, "v[224:227]", "v[228:231]")                                              \
-            GPUAR_DECODE_RUN8(3, w6, w7, 1, "v[232:235]", "v[236:239]")                                              \
+            /* what a step leaves to the next one's first shadow: the path after six decisions (written by every step of   */ \
+            /* the body, read by all but the first; defined here, for the compiler, without an instruction)                */ \
+            uint32_t path6;                                                                                          \
+            asm volatile("" : "=v"(path6));                                                                          \
+            GPUAR_DECODE_RUN8(0, GPUAR_STEP_FIRST, GPUAR_STEP_MIDDLE, w0, w1, 2, "v[240:243]", "v[244:247]")         \
+            GPUAR_DECODE_RUN8(1, GPUAR_STEP_MIDDLE, GPUAR_STEP_MIDDLE, w2, w3, 3, "v[248:251]", "v[252:255]")        \
+            GPUAR_DECODE_RUN8(2, GPUAR_STEP_MIDDLE, GPUAR_STEP_MIDDLE, w4, w5, 0, "v[224:227]", "v[228:231]")        \
+            GPUAR_DECODE_RUN8(3, GPUAR_STEP_MIDDLE, GPUAR_STEP_LAST, w6, w7, 1, "v[232:235]", "v[236:239]")          \
             /* the block's 64 bytes leave TOGETHER, as four back-to-back 16-byte stores (a whole 64-byte sector: with two */ \
             /* stores per half block the L2 wrote 5 % and fetched 9 % more than the bytes): the first half's words wait,    */ \
             /* complemented, in k0..k7 (the path bits are the COMPLEMENTED symbol bits)                                     */ \
