@@ -634,24 +634,22 @@ struct CarryCoderLane {
         //     otherwise: decided -- the waiting dwords go out behind what was just stored (zeros behind a carry, else ones)
         //     key = nff ? 0 : ~0
         unsigned long long saved, rare, undecided;
-        uint32_t word, over, sent, t_mask, t_addr, t_swapped;
+        uint32_t over, sent, t_addr, t_swapped;
         {
             const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;
             wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
         }
         asm volatile(
             "s_and_saveexec_b64 %[sx], %[m]\n\t"
-            "v_alignbit_b32 %[word], %[wh], %[wl], %[held]\n\t"
             "v_lshrrev_b32 %[over], %[held], %[wh]\n\t"
-            "v_cmp_ge_u32 %[rare], %[word], %[key]\n\t"                  /* (bits of lanes that do not store stay 0) */
-            "v_bfm_b32 %[tm], %[held], 0\n\t"
-            "v_add_u32 %[sent], %[cache], %[over]\n\t"
+            "v_add_u32 %[sent], %[cache], %[over]\n\t"                   /* what goes to memory: the dword kept back + the carry found now */
+            "v_alignbit_b32 %[cache], %[wh], %[wl], %[held]\n\t"         /* the leaving dword is the one kept back from here on */
+            "v_cmp_ge_u32 %[rare], %[cache], %[key]\n\t"                 /* (bits of lanes that do not store stay 0) */
             "v_min_u32 %[ta], %[at], %[last]\n\t"
             "v_perm_b32 %[tw], 0, %[sent], %[sel]\n\t"
             "global_store_dword %[ta], %[tw], %[base]\n\t"
-            "v_and_b32 %[wl], %[wl], %[tm]\n\t"
+            "v_bfe_u32 %[wl], %[wl], 0, %[held]\n\t"                     /* the window keeps what is below the dword that left */
             "v_mov_b32 %[wh], 0\n\t"
-            "v_mov_b32 %[cache], %[word]\n\t"
             "v_add_u32 %[at], 4, %[at]\n\t"
             "v_add_u32 %[held], -32, %[held]\n\t"
             "s_or_b64 exec, exec, %[sx]\n\t"
@@ -660,7 +658,7 @@ struct CarryCoderLane {
             "s_cbranch_scc1 .Lgpuar_common_%=\n\t"
             "s_mov_b64 %[sx], exec\n\t"
             "s_mov_b64 exec, %[rare]\n\t"
-            "v_cmp_eq_u32 vcc, -1, %[word]\n\t"
+            "v_cmp_eq_u32 vcc, -1, %[cache]\n\t"
             "v_cmp_eq_u32 %[und], 0, %[over]\n\t"
             "v_cndmask_b32 %[tw], 0, -1, %[und]\n\t"                    /* what waiting dwords turn into: ones, zeros behind a carry */
             "s_and_b64 %[und], %[und], vcc\n\t"
@@ -686,7 +684,7 @@ struct CarryCoderLane {
             ".Lgpuar_common_%=:"
 #endif
             : [wl] "+v"(wl), [wh] "+v"(wh), [at] "+v"(at), [held] "+v"(held), [cache] "+v"(cache), [nff] "+v"(nff), [key] "+v"(key),
-              [word] "=&v"(word), [over] "=&v"(over), [sent] "=&v"(sent), [tm] "=&v"(t_mask), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped),
+              [over] "=&v"(over), [sent] "=&v"(sent), [ta] "=&v"(t_addr), [tw] "=&v"(t_swapped),
               [sx] "=&s"(saved), [rare] "=&s"(rare), [und] "=&s"(undecided)
             : [m] "s"(full), [last] "v"(last), [sel] "s"(0x00010203u), [base] "s"(base)
             : "memory", "vcc", "scc");
