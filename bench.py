@@ -271,7 +271,7 @@ def measure_copy_peak(H, d_src, d_dst, n_bytes, reps=10):
 def annotate_roofs(result, copy_peak, traffic_source):
     """Every roofline* object of the line gets the roof measured in this run next to the datasheet's, and says which of
     its fields were measured live and which are replayed from a stamped profile record."""
-    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step")
+    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step")
     for key, r in result.items():
         if not (key.startswith("roofline") and isinstance(r, dict)):
             continue
@@ -415,7 +415,7 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
         r = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
              "algorithmic_bytes_per_launch": algo_bytes, "traffic": t.get("hbm_bytes_per_launch")}
         # the roof that actually binds (SURVEY.md section 7 risk 1): vector-issue and wait share of the wavefronts' cycles
-        for k in ("valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step"):
+        for k in ("valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step"):
             if k in t:
                 r[k] = t[k]
         return r
