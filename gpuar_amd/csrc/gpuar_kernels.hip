@@ -470,8 +470,8 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 //
 // Such a launch takes as long as ONE packet: 8192 serial symbol steps of the slowest role, whatever the chip could do
 // next to it -- the three-role kernel above needs ~355 cycles per step there (its coder's own chain), the same for 64
-// packets as for 65536.  With the chip mostly idle and LDS plentiful, the step is cut finer instead: SIX wavefronts
-// per 64 packets, each one phase (8 symbols) behind the one before it.  A wavefront with few neighbours pays ~4.5
+// packets as for 65536.  With the chip mostly idle and LDS plentiful, the step is cut finer instead: SIX working wavefronts
+// per 64 packets, each one phase (16 symbols) behind the one before it.  A wavefront with few neighbours pays ~4.5
 // cycles per vector instruction AND 12-20 per LDS operation, so the tree -- two LDS operations per
 // level -- is what has to be spread thinnest:
 //     UPPER    depths 1-2 of the tree; reads the input, hands the bytes on            13 vector + 5.5 LDS per symbol
@@ -483,22 +483,29 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
 //     COURIER  (seventh wavefront) INTERVAL's reciprocals from the table into LDS, a phase ahead: no scalar load in a working role
 // Same integers as the throughput kernel (lane_codec.h is shared; tests/test_lane_emulation.py pins the cut coder
 // and a three-way tree against the oracle on the CPU), a different cut.  Rings: five slots of sums, four of input
-// bytes, two of interval words: 48 KiB of LDS per workgroup.  Every role meets n_phases + 5 barriers.
+// bytes, two of interval words: 64 KiB of LDS per workgroup with the tree.  Every role meets n_phases + 5 barriers.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSmallGroups = 512;       // up to 32768 packets = 256 MiB of input: at most two workgroups per CU
-constexpr uint32_t kSmallLag = 5;            // the last role works five phases behind the first
-constexpr uint32_t kSumSlots = kSmallLag;    // a slot of sums is alive from UPPER's phase to INTERVAL's, four phases later
-constexpr uint32_t kByteBufs = 4;            // the bytes of a phase are read by MID1, MID2 and LOW, up to three phases later
+// (Measured and not kept, round 4: ONE tree level per role -- seven tree roles, ten wavefronts, phases of 8 symbols: 0.81 ms for
+// 64 MiB against 0.71; every role reads and writes the sums and meets the barrier whatever it carries.)
+constexpr uint32_t kSmallTreeRoles = 4;      // UPPER (depths 1-2), MID1 (3-4), MID2 (5-6), LOW (7, 0, the x == 255 term)
+constexpr uint32_t kSmallLag = kSmallTreeRoles + 1u;   // the last role (SINK) works this many phases behind the first
+constexpr uint32_t kSumSlots = kSmallLag;    // a slot of sums is alive from UPPER's phase to INTERVAL's, kSmallLag - 1 phases later
+constexpr uint32_t kByteBufs = kSmallTreeRoles;   // the bytes of a phase are read by the other tree roles, up to kSmallTreeRoles - 1 phases later
+constexpr uint32_t kSmallWaves = kSmallTreeRoles + 3u;   // + INTERVAL, SINK, COURIER
 #ifndef GPUAR_SMALL_PHASE
-#define GPUAR_SMALL_PHASE 8
+#define GPUAR_SMALL_PHASE 16                 // (8: 0.71 ms for 64 MiB; 16: 0.68 -- half as many barriers; 64 KiB of LDS per workgroup then)
 #endif
 constexpr uint32_t kSmallPhase = GPUAR_SMALL_PHASE;   // symbols per phase: the roles meet at a barrier once per phase
-static_assert(kSmallPhase == 8, "the reciprocal courier's two slots (the tree's 256th row, 128 bytes) hold eight pairs each");
+static_assert(kSmallPhase == 8 || kSmallPhase == 16, "a phase is 2 or 4 input dwords; the courier's lanes carry one dword of reciprocals each");
 struct alignas(16) EncodeSmallLds {
     uint8_t tree[kTreeRows * kLanes * 2];     // 32 KiB
     uint32_t sums[kSumSlots][kSmallPhase][kLanes];    // [slot][symbol][lane], cumLo | cumHi << 16 in the making
     uint32_t bytes[kByteBufs][kSmallPhase / 4][kLanes];    // the input bytes of a phase
     uint32_t words[2][kSmallPhase][kLanes];   // CarryIntervalLane -> CarrySinkLane: dn | n << 16 per symbol
+    // (the courier's two slots -- INTERVAL's (multiplier, shift) pairs of a phase, up to 128 bytes -- are the tree's two unused
+    // rows: row 127, where depth 0 would live if it were not a register, and row 255)
+    __device__ uint32_t *recips(uint32_t parity) { return reinterpret_cast<uint32_t *>(tree + (parity ? 255u : 127u) * 128u); }
 };
 
 // the input bytes of one phase at in + at (a multiple of the phase length), zero beyond `len`
@@ -529,9 +536,10 @@ __device__ __forceinline__ uint32_t byte_of(const PhaseBytes &p, uint32_t j) {  
     return (p.w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
 }
 
+template <int kUpperDepths>
 __device__ __forceinline__ void small_upper(EncodeSmallLds &lds, const uint8_t *in, uint32_t lane, uint32_t len, uint32_t len_min,
                                             uint32_t n_phases) {
-    PartialModeler<7, 1, 2, 0, false> model;
+    PartialModeler<7, 1, kUpperDepths, 0, false> model;
     PhaseBytes cur, nxt = load_phase(in, 0, len);
     model.open(lds.tree, 2u * lane_column(lane), nxt.w[0] & 0xFFu);
     for (uint32_t k = 0; k < n_phases + kSmallLag; ++k) {
@@ -593,7 +601,7 @@ __device__ __forceinline__ void small_follow(EncodeSmallLds &lds, uint32_t lane,
     for (uint32_t b = lag; b < kSmallLag; ++b) lds_barrier();
 }
 
-__global__ void __launch_bounds__(7 * kLanes)
+__global__ void __launch_bounds__(kSmallWaves * kLanes)
 encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict__ dst, uint32_t n_packets, uint32_t *__restrict__ status) {
     __shared__ EncodeSmallLds lds;
     const size_t group = blockIdx.x;
@@ -610,30 +618,33 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
     // The dispatcher deals a workgroup's wavefronts round the four SIMDs: wavefronts 0 and 4 share one, 1 and 5 another;
     // the four tree roles pair up there (one's LDS operations issue under the other's vector instructions), the two
     // coder roles have a SIMD each.
+    constexpr uint32_t kWaveInterval = 2u, kWaveSink = 3u, kWaveCourier = 6u;
     if (wave == 1u) {
-        small_upper(lds, in, lane, len, len_min, n_phases);
+        small_upper<2>(lds, in, lane, len, len_min, n_phases);
     } else if (wave == 4u) {
         small_follow<PartialModeler<7, 3, 2, 0, false>>(lds, lane, len, len_min, n_phases, 1u);
     } else if (wave == 5u) {
         small_follow<PartialModeler<7, 5, 2, 0, false>>(lds, lane, len, len_min, n_phases, 2u);
     } else if (wave == 0u) {
         small_follow<DeepestModeler<7>>(lds, lane, len, len_min, n_phases, 3u);
-    } else if (wave == 6u) {
-        // The seventh wavefront carries INTERVAL's reciprocals (as encode_kernel's fourth carries the coder's): the eight pairs
+    } else if (wave == kWaveCourier) {
+        // The last wavefront carries INTERVAL's reciprocals (as encode_kernel's fourth carries the coder's): the eight pairs
         // of a phase go into one of two slots in the tree's unused 256th row one barrier before INTERVAL reads them, so that
         // the wavefront that owns the interval chain never waits for a scalar load.
-        uint32_t *courier = reinterpret_cast<uint32_t *>(lds.tree + 255u * 128u);
+        constexpr uint32_t kPhaseDwords = 2u * kSmallPhase;
         const uint32_t *table = reinterpret_cast<const uint32_t *>(g_recip.r);
-        const uint32_t lane16 = lane & 15u;
-        uint32_t carried = table[lane16];
+        const uint32_t mine = lane & (kPhaseDwords - 1u);
+        uint32_t carried = table[mine];
         for (uint32_t t = 0; t < n_phases + kSmallLag; ++t) {
-            // interval t: INTERVAL works on phase t - 3 during interval t + 1 and reads slot (t - 3) & 1 = (t + 1) & 1
-            if (lane < 16u) courier[((t + 1u) & 1u) * 16u + lane16] = carried;
-            const uint32_t next_phase = t >= 2u && t - 2u < n_phases ? t - 2u : 0u;
-            carried = table[next_phase * 16u + lane16];
+            // INTERVAL works on phase p during interval p + kSmallLag - 1 and reads slot p & 1: the pairs of phase
+            // t + 2 - kSmallLag are written during interval t (one barrier ahead), those of the phase behind it asked for
+            constexpr uint32_t kAhead = kSmallLag - 2u;
+            if (lane < kPhaseDwords) lds.recips((t + kAhead) & 1u)[mine] = carried;
+            const uint32_t next_phase = t + 1u >= kAhead && t + 1u - kAhead < n_phases ? t + 1u - kAhead : 0u;
+            carried = table[next_phase * kPhaseDwords + mine];
             lds_barrier();
         }
-    } else if (wave == 2u) {
+    } else if (wave == kWaveInterval) {
         CarryIntervalLane interval;
         interval.open();
         for (uint32_t b = 0; b < kSmallLag - 1u; ++b) lds_barrier();
@@ -647,7 +658,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
                 for (uint32_t j = 0; j < kSmallPhase; ++j) cums[j] = sums[j * kLanes];
                 Recip rc[kSmallPhase];
                 {
-                    const uint4 *slot = reinterpret_cast<const uint4 *>(lds.tree + 255u * 128u + (k & 1u) * 64u);
+                    const uint4 *slot = reinterpret_cast<const uint4 *>(lds.recips(k & 1u));
 #pragma unroll
                     for (uint32_t q = 0; q < kSmallPhase / 2; ++q) {
                         const uint4 v = slot[q];
@@ -667,7 +678,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             lds_barrier();
         }
         lds_barrier();
-    } else {
+    } else if (wave == kWaveSink) {
         CarrySinkLane sink;
         sink.open(dst + group * (kLanes * kSlot), lane * kSlot);
         for (uint32_t b = 0; b < kSmallLag; ++b) lds_barrier();
@@ -1513,7 +1524,7 @@ int gpuar_hip_encode_mode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots,
     // caller's `mode` is the only switch (no environment is read here).
     const bool latency = mode == GPUAR_MODE_LATENCY || (mode == GPUAR_MODE_AUTO && groups <= gpuar::kSmallGroups);
     if (latency) {
-        gpuar::encode_small_kernel<<<groups, 7 * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
+        gpuar::encode_small_kernel<<<groups, gpuar::kSmallWaves * gpuar::kLanes, 0, static_cast<hipStream_t>(stream)>>>(
             d_in, n_bytes, d_slots, static_cast<uint32_t>(n_packets), status);
         return check_launch();
     }

@@ -95,14 +95,14 @@ int emu_encode_slots_phased(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 }
 
 // The latency-mode encoder's five roles (encode_small_kernel): the tree dealt 3 + 3 + (0, 7, tail) to three modelers
-// that add their parts onto each other in phases of 8 symbols, the carry-form coder cut into CarryIntervalLane and
+// that add their parts onto each other in phases of 16 symbols, the carry-form coder cut into CarryIntervalLane and
 // CarrySinkLane joined by one word per symbol (dn | n << 16).
 int emu_encode_slots_split(const uint8_t *in, size_t n_bytes, uint8_t *slots)
 {
     int any_overflow = 0;
     const size_t np = (n_bytes + kPacket - 1) / kPacket;
     std::vector<uint16_t> table(kTreeRows);
-    constexpr uint32_t kPhase = 8;
+    constexpr uint32_t kPhase = 16;
     for (size_t p = 0; p < np; ++p) {
         const size_t off = p * kPacket;
         const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
