@@ -64,6 +64,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-mib", type=int, default=16, help="single-core CPU baseline sample")
     ap.add_argument("--no-scaling-extras", action="store_true",
                     help="N > 1: skip the other scaling mode's pass and the gather probe")
+    ap.add_argument("--no-by-kind", action="store_true", help="N = 1: skip the text(1) and zipf(1) passes (BASELINE configs[2], [4])")
+    ap.add_argument("--by-kind-steps", type=int, default=5, help="timed steps of each of the by-kind passes")
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="seconds init_process_group and the first barrier may take before the run gives up with one clear line")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="route barrier / MAX / all_gather through torch.distributed (RCCL) even at world size 1: the RCCL preflight")
     return ap.parse_args(argv)
 
 
@@ -97,6 +103,81 @@ def self_launch(argv, n_gpus):
     if lines:
         print(lines[-1])
     return child.returncode if child.returncode or lines else 1
+
+
+def device_count_error(n_ranks, n_devices, oversubscribe):
+    """The one line `--gpus N` dies with when the box has fewer GPUs than ranks (None: fine)."""
+    if oversubscribe or n_ranks <= n_devices:
+        return None
+    return (f"bench.py: --gpus {n_ranks} asks for {n_ranks} ranks, one per GPU, but this node has {n_devices} visible GPU(s) "
+            "(torch.cuda.device_count()); nothing was started.  (Tests that rehearse N ranks on one GPU set "
+            "GPUAR_OVERSUBSCRIBE_DEVICES=1.)")
+
+
+class Watchdog:
+    """A timer around a step that may hang in a transport: when it fires, `line()` is printed and the process exits `code`."""
+
+    def __init__(self, seconds, line, code):
+        def fire():
+            print(line() if callable(line) else line, file=sys.stderr if code else sys.stdout, flush=True)
+            os._exit(code)
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+
+class Control:
+    """The control plane of a run: barrier, MAX over ranks, one int64 row per rank.  With one rank and no
+    --force-collectives it is plain Python; otherwise every call goes through torch.distributed -- RCCL ("nccl") on a real
+    run, gloo when GPUAR_OVERSUBSCRIBE_DEVICES=1 lets several ranks share one GPU in tests."""
+
+    def __init__(self, dist, world, rank, ctl_dev, active, backend, device_sync=None):
+        self.dist, self.world, self.rank, self.ctl_dev, self.active, self.backend = dist, world, rank, ctl_dev, active, backend
+        self.device_sync = device_sync      # None: torch.cuda.synchronize (the CPU rehearsal of the control plane passes a no-op)
+        self.on_rccl = active and backend == "nccl"
+        self.calls = {"barrier": 0, "all_reduce_max": 0, "all_reduce_min": 0, "all_gather": 0}
+
+    def barrier(self):
+        import torch
+        if self.active:
+            self.dist.barrier()
+            self.calls["barrier"] += 1
+        (self.device_sync or torch.cuda.synchronize)()
+
+    def _reduce(self, value, dtype, op, name):
+        import torch
+        if not self.active:
+            return value
+        t = torch.tensor([value], dtype=dtype, device=self.ctl_dev)
+        self.dist.all_reduce(t, op=op)
+        self.calls[name] += 1
+        return t.item()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        return float(self._reduce(seconds, torch.float64, self.dist.ReduceOp.MAX if self.active else None, "all_reduce_max"))
+
+    def min_over_ranks(self, count):
+        import torch
+        return int(self._reduce(count, torch.int64, self.dist.ReduceOp.MIN if self.active else None, "all_reduce_min"))
+
+    def gather_rows(self, row):
+        """all_gather of one int64 row per rank (rank order)."""
+        import torch
+        mine = torch.tensor(row, dtype=torch.int64, device=self.ctl_dev)
+        if not self.active:
+            return [mine.tolist()]
+        rows = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(rows, mine)
+        self.calls["all_gather"] += 1
+        return [r.tolist() for r in rows]
+
+    def report(self):
+        return {"backend": self.backend if self.active else None, "world": self.world, "through_torch_distributed": self.active,
+                "calls": dict(self.calls)}
 
 
 def plan_shard(args, world, rank):
@@ -268,11 +349,17 @@ def measure_copy_peak(H, d_src, d_dst, n_bytes, reps=10):
             "frac_of_datasheet_peak": 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
 
-def annotate_roofs(result, copy_peak, traffic_source):
-    """Every roofline* object of the line gets the roof measured in this run next to the datasheet's, and says which of
-    its fields were measured live and which are replayed from a stamped profile record."""
-    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step")
+def annotate_roofs(result, copy_peak, traffic_source=None):
+    """Every roofline* object of the line (the by_kind entries' too) gets the roof measured in this run next to the
+    datasheet's, and says which of its fields were measured live and which are replayed from a stamped profile record."""
+    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step",
+                "roofline_valu")
+    source = traffic_source if traffic_source is not None else result.get("traffic_source")
     for key, r in result.items():
+        if key == "by_kind" and isinstance(r, dict):
+            for entry in r.values():
+                annotate_roofs(entry, copy_peak)
+            continue
         if not (key.startswith("roofline") and isinstance(r, dict)):
             continue
         if copy_peak:
@@ -281,7 +368,7 @@ def annotate_roofs(result, copy_peak, traffic_source):
         r["measured_live"] = "achieved, frac, peak_measured_copy, frac_of_measured (HIP events in this run)"
         have = [k for k in replayed if r.get(k) is not None]
         if have:
-            r["counters"] = (f"{', '.join(have)}: replayed from profiles/{traffic_source} -- rocprofv3 PMC passes cannot run inside "
+            r["counters"] = (f"{', '.join(have)}: replayed from profiles/{source} -- rocprofv3 PMC passes cannot run inside "
                              "this process; the record is quoted only while its kernel-source stamp matches the built sources")
         else:
             r["counters"] = "none quoted (no profile record taken on this workload and these kernel sources)"
@@ -320,17 +407,15 @@ def side_kernels(H, d_in, d_slots, d_out, npk, n, reps):
     return out, d_stream, d_off, c
 
 
-def gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl):
+def gather_probe(ctl, d_stream, c_bytes):
     """north_star: "RCCL over xGMI only if a gather is measurably cheaper than staged hipMemcpyAsync" -- measured,
     on a bounded sample of every rank's compacted segment:
       staged  : every rank copies its segment to its OWN pinned host buffer over its own PCIe link, all at once
       gathered: every rank sends its segment to rank 0 (RCCL send/recv over xGMI), rank 0 copies the whole to the host
     Both leave all segments in host memory, ready for the ordered write.  Times are the MAX over ranks."""
     import torch
-    t = torch.tensor([min(c_bytes, 256 << 20)], dtype=torch.int64, device=ctl_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    sample = int(t.item()) // 4096 * 4096
+    dist, world, rank, on_rccl = ctl.dist, ctl.world, ctl.rank, ctl.on_rccl
+    sample = ctl.min_over_ranks(min(c_bytes, 256 << 20)) // 4096 * 4096
     seg = d_stream[:sample]
     dev = seg.device
     h_own = torch.empty(sample, dtype=torch.uint8, pin_memory=True)
@@ -339,14 +424,9 @@ def gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ctl.barrier()
 
-    def max_over_ranks(sec):
-        v = torch.tensor([sec], dtype=torch.float64, device=ctl_dev)
-        if world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        return float(v.item())
+    max_over_ranks = ctl.max_over_ranks
 
     def staged():
         h_own.copy_(seg, non_blocking=True)
@@ -398,8 +478,51 @@ def gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl):
     return res
 
 
+# What the hot path is really bound by (SURVEY.md section 7 risk 1, section 8(d) "report VALUBusy ... next to the HBM figure"): the
+# integer vector pipes.  A gfx950 SIMD retires 16 lanes of one vector instruction per cycle (a wave64 instruction occupies it
+# for four), so the chip's roof in lane-operations is CUs x 4 SIMDs x 16 lanes x shader clock; the path's demand is the
+# vector instructions one wavefront issues per symbol step (64 lanes advance 64 bytes: instructions per step = lane-ops per
+# byte), counted by rocprofv3 (SQ_INSTS_VALU) and replayed from the stamped profile record.
+MI355X_CUS = 256
+SHADER_CLOCK_GHZ = 2.4              # peak engine clock of the MI355X datasheet (/opt/skills/guides/MI355X_MICROARCH.md); the clock under
+                                    # this load was measured at 2.2-2.4 GHz (tools/lat_probe.hip)
+SMALL_GROUPS = 512                  # gpuar_hip_encode (GPUAR_MODE_AUTO) takes the latency kernel up to this many groups of 64 packets
+
+
+def kernel_symbols(n_packets):
+    """The symbols rocprofv3 lists for this launch size (profiles/*_kernel_stats.csv)."""
+    groups = (n_packets + 63) // 64
+    return {"encode": "encode_small_kernel" if groups <= SMALL_GROUPS else "encode_kernel", "decode": "decode_slots_kernel"}
+
+
+def valu_roof(lane_ops_per_byte, n_bytes, ms, cus=MI355X_CUS, clock_ghz=SHADER_CLOCK_GHZ):
+    """roofline_valu: the vector-issue roof.  achieved = lane-ops per byte (replayed counter) x bytes per launch / launch time."""
+    peak = cus * 4 * 16 * clock_ghz * 1e9
+    achieved = lane_ops_per_byte * n_bytes / (ms * 1e-3)
+    return {"bound": "valu", "lane_ops_per_byte": lane_ops_per_byte, "achieved_lane_ops_per_s": achieved, "peak_lane_ops_per_s": peak,
+            "frac": achieved / peak, "unit": "lane-ops/s",
+            "peak_from": f"{cus} CUs x 4 SIMDs x 16 lanes x {clock_ghz:g} GHz (datasheet peak engine clock, not measured in this run)",
+            "lane_ops_per_byte_from": "SQ_INSTS_VALU per symbol step of a wavefront (64 lanes, 64 bytes), replayed profile record"}
+
+
+def coder_roof(algo_bytes, n_bytes, ms, counters, kernel, machine=None):
+    """A roofline object of one of the two coder kernels: the HBM figure the contract asks for, the counters replayed
+    from the stamped profile record, and -- when that record holds the instruction count -- the roof that binds."""
+    a = algo_bytes / (ms * 1e-3) / 1e9
+    t = counters or {}
+    r = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+         "algorithmic_bytes_per_launch": algo_bytes, "traffic": t.get("hbm_bytes_per_launch"), "kernel": kernel}
+    # the roof that actually binds (SURVEY.md section 7 risk 1): vector-issue and wait share of the wavefronts' cycles
+    for k in ("valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step"):
+        if k in t:
+            r[k] = t[k]
+    if "valu_insts_per_symbol_step" in t:
+        r["roofline_valu"] = valu_roof(t["valu_insts_per_symbol_step"], n_bytes, ms, **(machine or {}))
+    return r
+
+
 def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_rank0, elapsed, enc_ms, dec_ms,
-                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic):
+                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic, machine=None):
     """The JSON line, from plain numbers (no GPU objects): the driver's contract fields, the roofline of
     the dominant kernel and what was verified.  enc_ms / dec_ms are rank 0's average launch durations over
     its shard of `shard_bytes` bytes; elapsed is the MAX over ranks of the wall time of args.steps steps."""
@@ -408,17 +531,10 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
     # dominant kernel = the slower of the two; algorithmic bytes per launch = N read/written + C written/read
     dom = "decode" if dec_ms >= enc_ms else "encode"
     algo_bytes = shard_bytes + c_bytes_rank0
+    symbols = kernel_symbols(npk_rank0)
 
     def roof(ms, which):
-        a = algo_bytes / (ms * 1e-3) / 1e9
-        t = traffic.get(which) or {}
-        r = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
-             "algorithmic_bytes_per_launch": algo_bytes, "traffic": t.get("hbm_bytes_per_launch")}
-        # the roof that actually binds (SURVEY.md section 7 risk 1): vector-issue and wait share of the wavefronts' cycles
-        for k in ("valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step"):
-            if k in t:
-                r[k] = t[k]
-        return r
+        return coder_roof(algo_bytes, shard_bytes, ms, traffic.get(which), symbols[which], machine)
 
     if args.scaling == "strong":
         work = (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPU(s), 8192-byte packets, "
@@ -441,18 +557,49 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
         "compression_ratio": (c_total + 20) / total_bytes,
         "roundtrip_equal": all_ok, "md5_sample_match": md5_in == md5_out, "md5_sample": md5_in,
         "oracle_prefix_match": oracle_ok, "device_status": status,
-        "roofline": dict(roof(dec_ms if dom == "decode" else enc_ms, dom), kernel=f"{dom}_kernel"),
+        "roofline": roof(dec_ms if dom == "decode" else enc_ms, dom),
         "roofline_encode": roof(enc_ms, "encode"), "roofline_decode": roof(dec_ms, "decode"),
         "traffic_source": traffic.get("source"),
     }
 
 
-def run_pass(args, H, dist, world, rank, dev, ctl_dev, steps, warmup):
+def kind_result(kind, seed, n, steps, elapsed, enc_ms, dec_ms, c_bytes, roundtrip_equal, oracle_ok, status, traffic, machine=None):
+    """One entry of `by_kind`: the same hot path on another of BASELINE.json's single-GPU workloads (configs[2] text,
+    configs[4]'s stream kind zipf), timed in the same run as the headline pass and assembled from plain numbers."""
+    symbols = kernel_symbols((n + 8191) // 8192)
+    algo = n + c_bytes
+    dom = "decode" if dec_ms >= enc_ms else "encode"
+    return {
+        "workload": f"{kind}({seed}) {n / GIB:g} GiB on 1 GPU, 8192-byte packets",
+        "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": n * steps / elapsed / 1e9, "unit": "GB/s",
+        "encode_ms": enc_ms, "decode_ms": dec_ms,
+        "encode_GBps": n / (enc_ms * 1e-3) / 1e9, "decode_GBps": n / (dec_ms * 1e-3) / 1e9,
+        "compression_ratio": (c_bytes + 20) / n, "roundtrip_equal": roundtrip_equal, "oracle_prefix_match": oracle_ok,
+        "device_status": status,
+        "roofline": coder_roof(algo, n, dec_ms if dom == "decode" else enc_ms, traffic.get(dom), symbols[dom], machine),
+        "roofline_encode": coder_roof(algo, n, enc_ms, traffic.get("encode"), symbols["encode"], machine),
+        "roofline_decode": coder_roof(algo, n, dec_ms, traffic.get("decode"), symbols["decode"], machine),
+        "traffic_source": traffic.get("source"),
+    }
+
+
+def oracle_prefix_ok(H, d_in, n, npk, d_stream, d_off, packets=64):
+    """The first `packets` packets of the compacted stream against the oracle on the same bytes (checker only, untimed)."""
+    from oracle import oracle as O
+    k = min(packets, npk)
+    host = d_in[:min(n, k * H.PACKET)].cpu().numpy()
+    want = O.best().encode_stream(host)
+    got = d_stream[:int(d_off[k].item())].cpu().numpy()
+    return bool(got.size == want.size and (got == want).all())
+
+
+def run_pass(args, H, ctl, dev, steps, warmup):
     """One measurement of the hot path under args.scaling: this rank's shard generated on the device, W untimed
     warm-up steps, then exactly `steps` steps (encode kernel + decode kernel) bracketed by barrier +
     torch.cuda.synchronize(), MAX over ranks; then, untimed, the per-kernel durations and the checks of what was
     just timed.  Returns plain numbers plus the device buffers (for the side kernels and the gather probe)."""
     import torch
+    world, rank = ctl.world, ctl.rank
     offset, n = plan_shard(args, world, rank)
     if n == 0:
         raise SystemExit(f"rank {rank} has no packets: too little data for {world} GPUs")
@@ -468,11 +615,7 @@ def run_pass(args, H, dist, world, rank, dev, ctl_dev, steps, warmup):
     def decode():
         H.decode(d_slots, npk, d_out, d_status=word)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = ctl.barrier                                     # dist.barrier() (when there is a process group) + torch.cuda.synchronize()
     for _ in range(warmup):
         encode()
         decode()
@@ -482,11 +625,7 @@ def run_pass(args, H, dist, world, rank, dev, ctl_dev, steps, warmup):
         encode()
         decode()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctl.max_over_ranks(time.perf_counter() - t0)
 
     # ---- per-kernel durations (HIP events on the launch stream), untimed region ----
     reps = max(3, min(steps, 10))
@@ -506,22 +645,38 @@ def run_pass(args, H, dist, world, rank, dev, ctl_dev, steps, warmup):
             "d_in": d_in, "d_slots": d_slots, "d_out": d_out}
 
 
-def gather_rows(dist, world, ctl_dev, row):
-    """all_gather of one int64 row per rank (rank order)."""
+def by_kind_pass(args, H, ctl, dev, kind, seed, machine):
+    """text(1) / zipf(1) at the headline pass's size (N = 1): W = 1 warm-up step, --by-kind-steps timed steps bracketed
+    like the headline pass, per-kernel durations from HIP events, round trip, compaction for the ratio, oracle prefix."""
     import torch
-    mine = torch.tensor(row, dtype=torch.int64, device=ctl_dev)
-    if world == 1:
-        return [mine.tolist()]
-    rows = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(rows, mine)
-    return [r.tolist() for r in rows]
+    a = argparse.Namespace(**vars(args))
+    a.kind, a.seed, a.scaling = kind, seed, "weak"
+    steps = max(1, args.by_kind_steps)
+    P = run_pass(a, H, ctl, dev, steps, 1)
+    n, npk = P["n"], P["npk"]
+    d_stream, d_off = H.compact(P["d_slots"], npk)
+    torch.cuda.synchronize()
+    c_bytes = int(d_off[-1].item())
+    ok = oracle_prefix_ok(H, P["d_in"], n, npk, d_stream, d_off)
+    traffic = load_profiled_traffic(kind, n)
+    res = kind_result(kind, seed, n, steps, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes,
+                      bool(P["roundtrip_equal"] and P["md5_in"] == P["md5_out"]), ok, P["status"], traffic, machine)
+    del P, d_stream, d_off
+    torch.cuda.empty_cache()
+    return res
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    oversubscribe = os.environ.get("GPUAR_OVERSUBSCRIBE_DEVICES") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # no launcher around us: become the launcher (children only; nothing here has touched the GPU)
+        # no launcher around us: become the launcher (children only; nothing here has touched the GPU --
+        # torch.cuda.device_count() does not initialise it on this image)
+        import torch
+        err = device_count_error(args.gpus, torch.cuda.device_count(), oversubscribe)
+        if err:
+            raise SystemExit(err)
         raise SystemExit(self_launch(argv, args.gpus))
 
     import torch
@@ -532,47 +687,65 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    n_devices = torch.cuda.device_count()
+    # a launcher gave this node more ranks than it has GPUs: every rank says so and leaves before any rendezvous
+    err = device_count_error(max(world, local_rank + 1), n_devices, oversubscribe)
+    if err:
+        raise SystemExit(err)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # Test hook: GPUAR_OVERSUBSCRIBE_DEVICES=1 lets several ranks share one physical GPU (rank -> device
     # rank % count) with gloo carrying the barrier/size exchange, so the N > 1 flow can be exercised on a
     # one-GPU box.  The driver's real runs use one GPU per rank and RCCL ("nccl").
-    oversubscribe = os.environ.get("GPUAR_OVERSUBSCRIBE_DEVICES") == "1"
-    local_dev = local_rank % torch.cuda.device_count() if oversubscribe else local_rank
+    local_dev = local_rank % n_devices if oversubscribe else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     ctl_dev = dev                      # where the control tensors of the collectives live
-    on_rccl = False
-    if world > 1:
+    collectives = world > 1 or args.force_collectives
+    backend = None
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                  # (--force-collectives without a launcher: a world of one)
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = "gloo" if oversubscribe else "nccl"
+        # The rendezvous, RCCL's start-up and the first collective are where a broken fabric hangs: they run under a timer
+        # of their own, and a rank that is not through in --init-timeout seconds says where it stood and exits 3.
+        where = {"at": "init_process_group"}
+        init_watchdog = Watchdog(args.init_timeout, lambda: (
+            f"bench.py: rank {rank} of {world} not through {where['at']} ({backend}) within {args.init_timeout:g} s: giving up "
+            "(MASTER_ADDR/MASTER_PORT reachable? HSA_ENABLE_IPC_MODE_LEGACY=0 exported? one GPU per rank?)"), 3)
         if oversubscribe:
             dist.init_process_group("gloo")
             ctl_dev = torch.device("cpu")
         else:
             dist.init_process_group("nccl", device_id=dev)
-            on_rccl = True
+        ctl = Control(dist, world, rank, ctl_dev, True, backend)
+        where["at"] = "the first barrier"
+        ctl.barrier()
+        init_watchdog.cancel()
+    else:
+        ctl = Control(dist, world, rank, ctl_dev, False, None)
     H.load()
+    props = torch.cuda.get_device_properties(dev)
+    machine = {"cus": int(getattr(props, "multi_processor_count", MI355X_CUS) or MI355X_CUS), "clock_ghz": SHADER_CLOCK_GHZ}
 
     # ---- the pass the contract's `value` comes from ----
-    P = run_pass(args, H, dist, world, rank, dev, ctl_dev, args.steps, args.warmup)
+    P = run_pass(args, H, ctl, dev, args.steps, args.warmup)
     n, npk = P["n"], P["npk"]
     # ---- the roof, measured on this box in this run: a plain device copy of the same buffer (rank 0's figure is quoted) ----
     copy_peak = measure_copy_peak(H, P["d_in"], P["d_out"], n) if rank == 0 else None
     # ---- the kernels either side (compaction, encode + compaction, decode from the stream), untimed region ----
     side, d_stream, d_off, c_bytes = side_kernels(H, P["d_in"], P["d_slots"], P["d_out"], npk, n, reps=5)
-    oracle_ok = None
-    if rank == 0:
-        from oracle import oracle as O
-        k = min(64, npk)
-        host = P["d_in"][:min(n, k * H.PACKET)].cpu().numpy()
-        want = O.best().encode_stream(host)
-        got = d_stream[:int(d_off[k].item())].cpu().numpy()
-        oracle_ok = bool(got.size == want.size and (got == want).all())
+    oracle_ok = oracle_prefix_ok(H, P["d_in"], n, npk, d_stream, d_off) if rank == 0 else None
 
     # one row per rank: [ok, compressed bytes, shard bytes, 1, encode us, decode us]; column 3 counts the ranks the
     # collective really saw
     ok = int(P["roundtrip_equal"] and P["status"] == 0 and P["md5_in"] == P["md5_out"] and side["decode_stream_roundtrip_equal"])
-    rows = gather_rows(dist, world, ctl_dev, [ok, c_bytes, n, 1, int(P["enc_ms"] * 1e3), int(P["dec_ms"] * 1e3)])
+    rows = ctl.gather_rows([ok, c_bytes, n, 1, int(P["enc_ms"] * 1e3), int(P["dec_ms"] * 1e3)])
     all_ok = all(r[0] == 1 for r in rows)
     c_total = sum(r[1] for r in rows)
     total_bytes = sum(r[2] for r in rows)
@@ -582,39 +755,41 @@ def main(argv=None):
     if rank == 0:
         traffic = load_profiled_traffic(args.kind, n)
         result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes, c_total,
-                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic)
+                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic, machine)
         result.update(side)
         for key, rec in (("roofline_compact", "gather"), ("roofline_decode_stream", "decode_stream")):
             if rec in traffic:                      # the PMC passes cover these kernels too (tools/prof_run.py --only all)
                 result[key]["traffic"] = traffic[rec].get("hbm_bytes_per_launch")
         result["hbm_copy_peak"] = copy_peak
-        annotate_roofs(result, copy_peak, traffic.get("source"))
         result["per_rank"] = {
             "encode_ms_min": min(r[4] for r in rows) / 1e3, "encode_ms_max": max(r[4] for r in rows) / 1e3,
             "decode_ms_min": min(r[5] for r in rows) / 1e3, "decode_ms_max": max(r[5] for r in rows) / 1e3,
             "compressed_bytes": [r[1] for r in rows],
         }
 
+    def finish_line():
+        annotate_roofs(result, copy_peak)
+        result["collectives"] = ctl.report()
+        return json.dumps(result)
+
     # ---- N > 1: the OTHER scaling mode in the same run (configs[3] strong: 8 GiB over N; configs[4] weak: 8 GiB each),
     #      and the measurement behind "RCCL only if a gather is measurably cheaper than staged hipMemcpyAsync" ----
     if world > 1 and not args.no_scaling_extras:
         # These extras must never cost the run its line: if they are not through within --extras-timeout seconds (a
         # transport that hangs), every rank's own timer fires, rank 0 prints what the timed pass measured, and all exit.
-        def bail():
-            if rank == 0:
-                result["scaling_extras"] = f"not finished within {args.extras_timeout} s: left out"
-                print(json.dumps(result), flush=True)
-            os._exit(0 if all_ok else 1)
-        watchdog = threading.Timer(args.extras_timeout, bail)
-        watchdog.daemon = True
-        watchdog.start()
-        probe = gather_probe(dist, world, rank, d_stream, c_bytes, ctl_dev, on_rccl)
+        def line_without_extras():
+            if rank != 0:
+                return f"bench.py: rank {rank}: scaling extras not finished within {args.extras_timeout} s"
+            result["scaling_extras"] = f"not finished within {args.extras_timeout} s: left out"
+            return finish_line()
+        watchdog = Watchdog(args.extras_timeout, line_without_extras, 0 if all_ok else 1)
+        probe = gather_probe(ctl, d_stream, c_bytes)
         del d_stream, d_off, P
         torch.cuda.empty_cache()
         other = argparse.Namespace(**vars(args))
         other.scaling = "strong" if args.scaling == "weak" else "weak"
-        Q = run_pass(other, H, dist, world, rank, dev, ctl_dev, max(3, args.steps // 4), 1)
-        q_rows = gather_rows(dist, world, ctl_dev, [int(Q["roundtrip_equal"] and Q["status"] == 0), Q["n"]])
+        Q = run_pass(other, H, ctl, dev, max(3, args.steps // 4), 1)
+        q_rows = ctl.gather_rows([int(Q["roundtrip_equal"] and Q["status"] == 0), Q["n"]])
         if rank == 0:
             q_total = sum(r[1] for r in q_rows)
             q_steps = max(3, args.steps // 4)
@@ -630,8 +805,19 @@ def main(argv=None):
         watchdog.cancel()
         del Q
     else:
+        if args.force_collectives and rank == 0:             # the RCCL preflight: the gather probe's collectives at whatever world this is
+            result["gather_probe"] = gather_probe(ctl, d_stream, c_bytes)
         del d_stream, d_off, P
     torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs[2] and [4]'s stream kinds at the same size, N = 1 only (the other ranks would sit at a barrier) ----
+    if rank == 0 and world == 1 and not args.no_by_kind:
+        result["by_kind"] = {}
+        for kind, seed in (("text", 1), ("zipf", 1)):
+            if kind == args.kind and seed == args.seed:
+                continue
+            result["by_kind"][kind] = by_kind_pass(args, H, ctl, dev, kind, seed, machine)
+            all_ok = all_ok and result["by_kind"][kind]["roundtrip_equal"] and result["by_kind"][kind]["device_status"] == 0
 
     # ---- configs[1]: the 64 MiB stand-in for data/random_64m.dat, rank 0 only ----
     if rank == 0 and not args.no_small_config:
@@ -658,8 +844,8 @@ def main(argv=None):
         result["cpu_baseline"] = cpu_baseline(args.kind, args.seed, args.cpu_sample_mib << 20)
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        print(finish_line(), flush=True)
+    if ctl.active:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not all_ok:

@@ -6,22 +6,23 @@
 // (/root/reference/src/gpuar_kernel.cu:894-934, 205-238, 321-367, 787-836) is
 // re-derived here for 64-wide wavefronts (per-lane code: lane_codec.h):
 //
-//  * encode_kernel: three working wavefronts per 64 packets -- two MODELERS
-//    (adaptive models in LDS: per lane a binary left-count tree, node-major/
-//    lane-minor so lane l always hits bank l & 31; software-pipelined walks
-//    over depths 1-6 and {0, 7} that yield cumLo, cumHi and the count update)
-//    and a CODER (interval narrowing by a wave-uniform reciprocal, closed-form
-//    renormalisation, bit sink), one phase apart from each other and handing a
-//    phase on in place through a three-slot LDS ring; a fourth, idle
-//    wavefront makes the workgroup cover all four SIMDs so that roles can be
-//    dealt out per SIMD;
-//  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads
-//    two 16-byte subtree records per symbol instead of walking eight levels, applies
-//    the increments of the 8-byte half of each that the path went through by one 64-bit LDS add, and
-//    works on a scaled remainder (no division, borrow = path bit); the symbol step
-//    is a hand-scheduled instruction stream; the packet stream reaches it through a
-//    per-lane ring in LDS, the per-symbol constants through v_readlane;
-//  * compaction (scan + gather) and synthetic-stream generators.
+//  * encode_kernel (throughput): four wavefronts per 64 packets, one role per SIMD -- a TOP MODELER (reads the input,
+//    walks depths 1-4 of the 64 adaptive models: per lane a binary left-count tree in LDS, node-major / lane-minor so
+//    that lane l always hits bank l & 31; software-pipelined walks that yield cumLo, cumHi and the count update), a
+//    LOW MODELER (depth 0 in a register, depths 5-7, the x == 255 term, added onto the top modeler's part in place), a
+//    CODER (interval narrowing by a wave-uniform reciprocal, one-clz renormalisation count, the lower bound as a 64-bit
+//    window with carries, predicated dword stores) and a COURIER that carries the coder's reciprocals from memory into
+//    LDS a phase ahead, so that no working role issues a scalar load.  The roles work one phase (8 symbols) apart and
+//    hand a phase on in place through a three-slot LDS ring, one s_barrier per phase;
+//  * encode_small_kernel (latency): the same integers cut finer for inputs that cannot fill the chip -- four tree
+//    roles, an interval role, a sink role and a courier, seven wavefronts per 64 packets, phases of 16 symbols;
+//  * decode_*_kernel: one wavefront per 64 packets; the symbol search reads two 16-byte subtree records per symbol
+//    instead of walking eight levels, applies the increments of the 8-byte half of each that the path went through by
+//    one 64-bit LDS add, and works on a scaled remainder (no division, borrow = path bit); the symbol step is a
+//    hand-scheduled instruction stream; the packet stream reaches it through a per-lane ring in LDS, the per-symbol
+//    reciprocal multipliers as VECTOR operands, eight at a time by loads with a wave-uniform address (no scalar load,
+//    no v_readlane in the loop);
+//  * compaction (scan + gather), synthetic-stream generators, a plain copy (the measured HBM roof).
 //
 // Bit-exact with the reference: same counts, same integer arithmetic, same
 // bitstream.  No MFMA: this is integer, bit-serial
@@ -1520,7 +1521,7 @@ int gpuar_hip_encode_mode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots,
     if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t groups = static_cast<uint32_t>((n_packets + gpuar::kLanes - 1) / gpuar::kLanes);
     // Small inputs cannot fill the chip and take as long as one packet: left to itself (GPUAR_MODE_AUTO) such a launch
-    // goes to the latency-mode kernel (six roles, a shorter step).  The slots are the same bytes either way; the
+    // goes to the latency-mode kernel (six working roles and a courier, a shorter step).  The slots are the same bytes either way; the
     // caller's `mode` is the only switch (no environment is read here).
     const bool latency = mode == GPUAR_MODE_LATENCY || (mode == GPUAR_MODE_AUTO && groups <= gpuar::kSmallGroups);
     if (latency) {
@@ -1565,7 +1566,9 @@ int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_strea
     if (!d_slots || !d_stream) return GPUAR_ERR_ARGUMENT;
     if (!aligned16(d_slots) || (reinterpret_cast<uintptr_t>(d_offsets) & 7u) || (reinterpret_cast<uintptr_t>(d_stream) & 7u))
         return GPUAR_ERR_ALIGNMENT;
-    if (n_packets > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
+    // the gather launches one workgroup per packet, and gridDim.x * blockDim.x must stay below 2^32 threads: 16.7 M packets
+    // = 128 GiB of input per call with 256-thread workgroups (a device holds 288 GB; the CLI compacts 512 MiB chunks)
+    if (n_packets * static_cast<size_t>(gpuar::kGatherThreads) > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const size_t tiles = (n_packets + gpuar::kScanTile - 1) / gpuar::kScanTile;
     const uint32_t np = static_cast<uint32_t>(n_packets);
     uint64_t *tile_prefix = reinterpret_cast<uint64_t *>(d_stream);   // scratch until the gather overwrites it
@@ -1654,7 +1657,9 @@ int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *s
     if (!aligned16(d_src) || !aligned16(d_dst)) return GPUAR_ERR_ALIGNMENT;
     const size_t n_quads = n_bytes / 16u;
     const size_t want = (n_quads + 255u) / 256u;                    // one quad per thread
-    if (want > 0x7FFFFFFFull) return GPUAR_ERR_ARGUMENT;             // 8 TiB: beyond any device
+    // HIP rejects a launch once gridDim.x * blockDim.x reaches 2^32 threads: 64 GiB less one tile for this kernel (bench.py
+    // copies its 8 GiB workload); beyond that the caller gets an argument error instead of a launch error
+    if (want * 256u > 0xFFFFFFFFull) return GPUAR_ERR_ARGUMENT;
     const uint32_t blocks = static_cast<uint32_t>(want);
     gpuar::copy_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(d_dst), n_quads);

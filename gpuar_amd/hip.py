@@ -84,8 +84,8 @@ def load() -> C.CDLL:
 
 def _mode_id(mode, env_var) -> int:
     """GPUAR_MODE_* for a call: the caller's `mode` ("auto" | "throughput" | "latency"), else the environment variable
-    that tests and tools use to pin a kernel (GPUAR_ENCODE_MODE / GPUAR_DECODE_MODE) -- read HERE, in the Python shim,
-    never inside the library --, else auto."""
+    that tests and tools use to pin the encode kernel (GPUAR_ENCODE_MODE; there is no decode mode) -- read HERE, in the
+    Python shim, never inside the library --, else auto."""
     name = mode if mode is not None else os.environ.get(env_var, "auto")
     if name not in MODE_ID:
         raise GpuarError(f"unknown kernel mode {name!r} (auto, throughput, latency)")

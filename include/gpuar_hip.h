@@ -100,16 +100,16 @@ size_t gpuar_hip_packet_count(size_t n_bytes);
  * (16-byte aligned, gpuar_hip_packet_count(n_bytes)*8704 bytes). */
 int gpuar_hip_encode(const uint8_t *d_in, size_t n_bytes, uint8_t *d_slots, uint32_t *d_status, void *stream);
 
-/* The same with the kernel named by the caller.  Both kernels write the same
- * bytes; they differ in how a launch is cut into wavefronts:
- *   GPUAR_MODE_THROUGHPUT  three working wavefronts per 64 packets (encode) / one per 64 packets (decode):
+/* The same with the ENCODE kernel named by the caller (there is one decode kernel per input layout and no
+ * decode mode).  Both encode kernels write the same bytes; they differ in how a launch is cut into wavefronts:
+ *   GPUAR_MODE_THROUGHPUT  three working wavefronts (and one that carries constants) per 64 packets:
  *                          the most bytes per second from a launch that fills the chip;
- *   GPUAR_MODE_LATENCY     a finer cut (encode: six wavefronts per 64 packets) with a shorter symbol step:
- *                          faster while the launch cannot fill the chip by itself;
- *   GPUAR_MODE_AUTO        what gpuar_hip_encode / gpuar_hip_decode do: LATENCY up to 32768 packets
- *                          (256 MiB of input), THROUGHPUT above -- right for a launch that has the
- *                          chip to itself; a pipeline that keeps several launches in flight names
- *                          THROUGHPUT.
+ *   GPUAR_MODE_LATENCY     a finer cut -- six working wavefronts (and a seventh that carries constants) per
+ *                          64 packets -- with a shorter symbol step: faster while the launch cannot fill
+ *                          the chip by itself;
+ *   GPUAR_MODE_AUTO        what gpuar_hip_encode does: LATENCY up to 32768 packets (256 MiB of input),
+ *                          THROUGHPUT above -- right for a launch that has the chip to itself; a pipeline
+ *                          that keeps several launches in flight names THROUGHPUT.
  * The choice is an argument, never an environment variable: this library reads no environment.
  * Any other `mode` is GPUAR_ERR_ARGUMENT. */
 #define GPUAR_MODE_AUTO        0
@@ -129,7 +129,8 @@ int gpuar_hip_decode(const uint8_t *d_slots, size_t n_packets, uint8_t *d_out, u
  * d_stream (8-byte aligned) needs room for the sum of clen (<= n_packets*8704);
  * its first bytes serve as scan scratch before the packets are gathered into
  * it, so the call keeps no state outside its arguments and may run
- * concurrently on different streams and devices. */
+ * concurrently on different streams and devices.  At most 16 777 215 packets
+ * (128 GiB of input) per call: GPUAR_ERR_ARGUMENT above. */
 int gpuar_hip_compact(const uint8_t *d_slots, size_t n_packets, uint8_t *d_stream,
                       uint64_t *d_offsets, void *stream);
 
@@ -169,7 +170,7 @@ int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8
 
 /* Measurement support: a plain device-to-device copy of n_bytes (a multiple of 16; both pointers 16-byte aligned),
  * 16 bytes per lane -- the practical HBM roof bench.py measures on the box and quotes next to the datasheet's
- * 8 TB/s.  Moves 2 * n_bytes through HBM. */
+ * 8 TB/s.  Moves 2 * n_bytes through HBM.  n_bytes < 64 GiB: GPUAR_ERR_ARGUMENT above. */
 int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *stream);
 
 #ifdef __cplusplus

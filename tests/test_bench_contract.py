@@ -36,7 +36,7 @@ def test_json_line_has_the_contract_fields_and_consistent_arithmetic():
     assert abs(d["value"] - 8 * GIB / 0.0709 / 1e9) < 1e-6            # value = bytes of all ranks / time
     r = d["roofline"]
     # dominant kernel = the slower one; achieved = (N + C) / its launch duration; frac = achieved / 8 TB/s
-    assert r["kernel"] == "decode_kernel" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["kernel"] == "decode_slots_kernel" and r["bound"] == "hbm"      # the symbol rocprofv3 lists, not a nickname and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["algorithmic_bytes_per_launch"] == 8 * GIB + 8658985568
     assert abs(r["achieved"] - (8 * GIB + 8658985568) / 46.3e-3 / 1e9) < 1e-6
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
@@ -142,3 +142,102 @@ def test_every_roofline_object_carries_the_measured_roof_and_says_what_is_replay
     assert "replayed from profiles/r09_traffic.json" in d["roofline"]["counters"] and "valu_busy" in d["roofline"]["counters"]
     assert d["roofline_compact"]["counters"].startswith("none quoted")
     json.dumps(d)
+
+
+def test_roofline_valu_says_the_binding_roof_outright():
+    """SURVEY.md section 8(d) "report VALUBusy ... next to the HBM figure": every coder roofline that has the instruction count
+    of its kernel (a replayed counter) also carries the vector-issue roof: lane-ops per byte x bytes / time against
+    CUs x 4 SIMDs x 16 lanes x clock."""
+    t = {"source": "r09_traffic.json: pmc",
+         "encode": {"hbm_bytes_per_launch": 1.98e10, "valu_insts_per_symbol_step": 77.9, "valu_busy_per_simd": 0.949},
+         "decode": {"hbm_bytes_per_launch": 1.87e10, "valu_insts_per_symbol_step": 83.25, "valu_busy_per_simd": 0.693}}
+    args = bench.parse_args([])
+    n, c = 8 * GIB, 8658985568
+    d = bench.assemble_result(args, 1, 1, n, n, n // 8192, elapsed=0.0447 * args.steps, enc_ms=18.15, dec_ms=26.47, c_bytes_rank0=c,
+                              c_total=c, all_ok=True, md5_in="x", md5_out="x", oracle_ok=True, status=0, traffic=t)
+    peak = 256 * 4 * 16 * 2.4e9
+    for key, ms, per_byte in (("roofline_encode", 18.15, 77.9), ("roofline_decode", 26.47, 83.25), ("roofline", 26.47, 83.25)):
+        v = d[key]["roofline_valu"]
+        assert v["bound"] == "valu" and v["lane_ops_per_byte"] == per_byte and v["peak_lane_ops_per_s"] == peak
+        assert abs(v["achieved_lane_ops_per_s"] - per_byte * n / (ms * 1e-3)) < 1e3
+        assert abs(v["frac"] - v["achieved_lane_ops_per_s"] / peak) < 1e-12
+    # the figures of VERDICT r4: the encoder at 94 % of the vector-issue roof, the decoder at 69 %
+    assert abs(d["roofline_encode"]["roofline_valu"]["frac"] - 0.94) < 0.01 and abs(d["roofline_decode"]["roofline_valu"]["frac"] - 0.69) < 0.01
+    assert d["roofline_encode"]["kernel"] == "encode_kernel" and d["roofline_decode"]["kernel"] == "decode_slots_kernel"
+    # no counter record -> no vector roof is made up
+    assert "roofline_valu" not in stub_line([])["roofline"]
+    # another machine shape is stated, not assumed
+    m = bench.valu_roof(80.0, GIB, 10.0, cus=128, clock_ghz=2.0)
+    assert m["peak_lane_ops_per_s"] == 128 * 4 * 16 * 2.0e9 and "128 CUs" in m["peak_from"]
+
+
+def test_kernel_symbols_follow_the_launch_size():
+    assert bench.kernel_symbols(8192)["encode"] == "encode_small_kernel"           # 64 MiB: 128 groups -> latency kernel
+    assert bench.kernel_symbols(512 * 64)["encode"] == "encode_small_kernel" and bench.kernel_symbols(512 * 64 + 1)["encode"] == "encode_kernel"
+    assert bench.kernel_symbols(1 << 20) == {"encode": "encode_kernel", "decode": "decode_slots_kernel"}
+
+
+def test_by_kind_entries_have_the_shape_the_driver_line_promises():
+    """BASELINE.json configs[2] (text) and configs[4]'s stream kind (zipf) ride in the same line as the uniform pass."""
+    t = {"source": "r09_traffic_text_8gib.json: pmc", "encode": {"hbm_bytes_per_launch": 1.5e10, "valu_insts_per_symbol_step": 78.0},
+         "decode": {"hbm_bytes_per_launch": 1.45e10, "valu_insts_per_symbol_step": 83.0}}
+    n, c = 8 * GIB, 5819484000
+    k = bench.kind_result("text", 1, n, 5, elapsed=5 * 0.0446, enc_ms=18.1, dec_ms=26.5, c_bytes=c, roundtrip_equal=True, oracle_ok=True,
+                          status=0, traffic=t)
+    for key in ("workload", "steps", "ms_per_step", "value", "unit", "encode_ms", "decode_ms", "encode_GBps", "decode_GBps", "compression_ratio",
+                "roundtrip_equal", "oracle_prefix_match", "device_status", "roofline", "roofline_encode", "roofline_decode", "traffic_source"):
+        assert key in k, key
+    assert k["workload"].startswith("text(1) 8 GiB") and k["unit"] == "GB/s" and k["steps"] == 5
+    assert abs(k["value"] - n / 0.0446 / 1e9) < 1e-6 and abs(k["compression_ratio"] - (c + 20) / n) < 1e-12
+    r = k["roofline"]
+    assert r["kernel"] == "decode_slots_kernel" and r["algorithmic_bytes_per_launch"] == n + c and r["traffic"] == 1.45e10
+    assert abs(r["achieved"] - (n + c) / 26.5e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert "roofline_valu" in r and "roofline_valu" in k["roofline_encode"]
+    line = stub_line([])
+    line["by_kind"] = {"text": k}
+    bench.annotate_roofs(line, {"GBps": 6200.0})
+    assert k["roofline"]["peak_measured_copy"] == 6200.0 and "r09_traffic_text_8gib.json" in k["roofline"]["counters"]
+    assert line["roofline"]["counters"].startswith("none quoted")
+    json.dumps(line)
+
+
+def test_more_ranks_than_gpus_is_refused_in_one_line_before_anything_starts(monkeypatch, capsys):
+    assert bench.device_count_error(8, 8, False) is None and bench.device_count_error(1, 1, False) is None
+    assert bench.device_count_error(4, 1, True) is None                          # the tests' oversubscription hook
+    msg = bench.device_count_error(8, 1, False)
+    assert "--gpus 8" in msg and "1 visible GPU" in msg and "\n" not in msg
+    # `python bench.py --gpus 8` on a box with fewer GPUs: exits non-zero with that line, and never builds a launch command
+    import torch
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("GPUAR_OVERSUBSCRIBE_DEVICES", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(bench, "self_launch", lambda *a, **k: (_ for _ in ()).throw(AssertionError("ranks were started")))
+    try:
+        bench.main(["--gpus", "8"])
+    except SystemExit as e:
+        assert isinstance(e.code, str) and "nothing was started" in e.code
+    else:
+        raise AssertionError("bench.main did not exit")
+
+
+def test_watchdog_prints_its_line_and_exits_with_its_code():
+    """The timer around init_process_group / the first barrier (and around the N > 1 extras): a rank that hangs there ends
+    with one clear line and the given exit code instead of sitting in the driver's run until its limit."""
+    import subprocess
+    code = ("import bench, time\n"
+            "w = bench.Watchdog(0.2, lambda: 'bench.py: rank 0 of 8 not through init_process_group', 3)\n"
+            "time.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=20)
+    assert r.returncode == 3 and "not through init_process_group" in r.stderr
+    code = "import bench, time\nw = bench.Watchdog(5, 'never', 3)\nw.cancel()\nprint('done')\n"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "done" in r.stdout
+
+
+def test_control_plane_without_a_process_group_is_plain_python():
+    """world = 1 without --force-collectives: no torch.distributed call is made; the report says so."""
+    import torch
+    c = bench.Control(None, 1, 0, torch.device("cpu"), False, None)
+    assert c.max_over_ranks(1.5) == 1.5 and c.min_over_ranks(7) == 7 and c.gather_rows([1, 2, 3]) == [[1, 2, 3]]
+    rep = c.report()
+    assert rep["through_torch_distributed"] is False and rep["backend"] is None and sum(rep["calls"].values()) == 0

@@ -187,6 +187,12 @@ def test_argument_errors(H):
     assert lib.gpuar_hip_encode(buf.data_ptr(), 0, buf.data_ptr(), None, None) == 0              # empty input: nothing to do
     lib.garCompressExecutor(buf.data_ptr() + 1, 100, buf.data_ptr(), 1)
     assert lib.gpuar_hip_last_error() == -1 and lib.gpuar_hip_last_error() == 0
+    # sizes whose launch would need 2^32 threads or more are refused as arguments, before any launch: the copy
+    # at 64 GiB (one 16-byte quad per thread), the compaction at 2^24 packets (one 256-thread workgroup per packet)
+    assert lib.gpuar_hip_copy(buf.data_ptr(), buf.data_ptr(), 64 << 30, None) == -2
+    assert lib.gpuar_hip_compact(buf.data_ptr(), 1 << 24, buf.data_ptr(), buf.data_ptr(), None) == -2
+    torch.cuda.synchronize()
+    assert lib.gpuar_hip_last_error() == 0 and H.status() == 0
 
 
 def test_malformed_packets_are_flagged_not_fatal(H):
@@ -396,6 +402,46 @@ def test_many_mixed_packets_against_oracle(H, oracle, encode_mode):
     assert int(d_off[-1].item()) == total
     assert np.array_equal(H.decode(d_slots, npk).cpu().numpy(), data)
     assert np.array_equal(H.decode_stream(d_stream, d_off, npk).cpu().numpy(), data)
+    assert H.status() == 0
+
+
+REAL_TEXT_GLOBS = ("*.md", "bench.py", "__graft_entry__.py", "gpuar_amd/*.py", "gpuar_amd/csrc/*.hip", "gpuar_amd/csrc/*.h",
+                   "gpuar_amd/csrc/Makefile", "gpuar_amd/csrc/host/*", "include/*.h", "oracle/*.c", "oracle/*.py", "oracle/*.cpp",
+                   "oracle/*.sh", "tests/*.py", "tests/*.cpp", "tools/*.hip", "tools/*.py", "tools/*.sh", "tools/*.cpp", "tools/*.md",
+                   "profiles/*.txt", "profiles/*.md")
+
+
+def real_text(min_bytes):
+    """This repository's own text -- sources, documents, profile summaries, in sorted path order -- repeated until it is at
+    least `min_bytes` long; copy k has every 1009th byte from position k on moved by k (still 7-bit), so no two copies hold
+    the same packets.  (The repository on the GPU box is the snapshot gpurun pushes: the same files, no .git.)"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted({f for pat in REAL_TEXT_GLOBS for f in glob.glob(os.path.join(root, pat)) if os.path.isfile(f)})
+    base = np.concatenate([np.fromfile(f, dtype=np.uint8) for f in files])
+    assert base.size > (1 << 20), "the repository's text shrank below 1 MiB?"
+    copies = []
+    for k in range((min_bytes + base.size - 1) // base.size):
+        c = base.copy()
+        c[k::1009] = (c[k::1009].astype(np.uint32) + k) % 128
+        copies.append(c)
+    return np.concatenate(copies), len(files)
+
+
+def test_real_text_against_oracle(H, oracle, encode_mode):
+    """Real bytes, once (SURVEY.md section 6's third probe row was source text; BASELINE.md section 2 row 3: ratio 0.5717): every
+    other GPU input is synthetic.  >= 32 MiB of this repository's own text through both encode kernels: the whole stream
+    byte-equal to the oracle's, both decoders, the ratio inside the band real source text lands in."""
+    data, n_files = real_text(32 << 20)
+    assert data.size >= (32 << 20) and n_files > 50
+    want = oracle.encode_stream(data)
+    stream, offs, d_slots, npk = gpu_stream(H, data)
+    assert stream.size == want.size and np.array_equal(stream, want), "packet stream differs from the oracle on real text"
+    ratio = (stream.size + 20) / data.size
+    assert 0.55 < ratio < 0.70, ratio
+    d_stream, d_off = H.compact(d_slots, npk)
+    assert np.array_equal(H.decode(d_slots, npk).cpu().numpy()[:data.size], data)
+    assert np.array_equal(H.decode_stream(d_stream, d_off, npk).cpu().numpy()[:data.size], data)
     assert H.status() == 0
 
 
@@ -626,6 +672,76 @@ def test_bench_four_rank_dry_run_on_one_gpu(tmp_path):
     assert d["other_scaling"]["total_bytes"] == world * (1 << 27)
     assert d["gather_probe"]["ranks"] == world and d["gather_probe"]["cheaper"] in ("staged hipMemcpyAsync", "RCCL gather")
     assert "hbm_copy_peak" in d and d["roofline"]["peak_measured_copy"] > 0
+
+
+def test_rccl_preflight_at_world_size_one(tmp_path):
+    """The first 8-GPU run must not be the first RCCL run: bench.py with --force-collectives brings up
+    init_process_group("nccl", device_id=...) -- RCCL -- on this box's one GPU as a world of ONE rank and routes its barrier,
+    the MAX of the elapsed time, the MIN of the sample size and the all_gather of the per-rank rows through it, with tensors
+    on the device.  What a world of one cannot rehearse is the point-to-point leg of the gather probe (batch_isend_irecv to
+    rank 0 needs a peer): that leg is skipped and the record says how many ranks it saw."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collectives", "--steps", "2", "--warmup", "1",
+           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-by-kind", "--init-timeout", "240"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["collectives"]
+    assert c["backend"] == "nccl" and c["through_torch_distributed"] is True and c["world"] == 1
+    # the first barrier behind init, two around the timed steps, eight inside the gather probe's timing loop ...
+    assert c["calls"]["barrier"] >= 3 and c["calls"]["all_reduce_max"] >= 1 and c["calls"]["all_reduce_min"] >= 1 and c["calls"]["all_gather"] >= 1
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
+    g = d["gather_probe"]
+    assert g["ranks"] == 1 and g["transport"].startswith("RCCL") and g["staged_d2h_ms"] > 0 and g["gather_then_d2h_ms"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_starting_any(tmp_path):
+    """`bench.py --gpus 8` on a box with one GPU and no oversubscription hook: one clear line, non-zero, within seconds --
+    no rank is spawned, no rendezvous is waited for."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "nothing was started" in r.stderr and "--gpus 8" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 120
+    # the same under a launcher that hands this node more ranks than it has GPUs: the rank says so before any rendezvous
+    env.update(WORLD_SIZE="8", RANK="5", LOCAL_RANK="5", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "nothing was started" in r.stderr
+
+
+def test_bench_line_carries_text_and_zipf_next_to_uniform(tmp_path):
+    """One driver-timed line for every single-GPU BASELINE workload: after the uniform pass, text(1) and
+    zipf(1) at the same size, each with its own times, ratio, round trip, oracle prefix and roofline objects."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--gib-per-gpu", "0.5", "--by-kind-steps", "2",
+           "--no-cpu-baseline", "--no-small-config"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["roofline"]["kernel"] in ("decode_slots_kernel", "encode_kernel") and d["roofline_encode"]["kernel"] == "encode_kernel"
+    assert d["collectives"]["through_torch_distributed"] is False
+    assert set(d["by_kind"]) == {"text", "zipf"}
+    for kind, lo, hi in (("text", 0.66, 0.69), ("zipf", 0.77, 0.80)):
+        k = d["by_kind"][kind]
+        assert k["roundtrip_equal"] is True and k["oracle_prefix_match"] is True and k["device_status"] == 0, kind
+        assert lo < k["compression_ratio"] < hi, (kind, k["compression_ratio"])
+        assert k["encode_ms"] > 0 and k["decode_ms"] > 0 and k["value"] > 0 and k["steps"] == 2
+        assert k["roofline"]["bound"] == "hbm" and k["roofline"]["peak_measured_copy"] > 0 and 0 < k["roofline"]["frac"] < 1
+        assert k["roofline"]["algorithmic_bytes_per_launch"] == (1 << 29) + round(k["compression_ratio"] * (1 << 29)) - 20
 
 
 def test_bench_strong_scaling_splits_one_stream(tmp_path):

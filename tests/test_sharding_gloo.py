@@ -72,8 +72,8 @@ def test_two_rank_segments_concatenate_to_the_whole_stream(kind, n):
 
 
 def _worker8(rank, world, port, q):
-    """One of EIGHT ranks of bench.py's control plane on CPU: bench.plan_shard for both scaling modes, bench.gather_rows
-    (the all_gather of one row per rank) and the MAX of the elapsed time -- the code paths `bench.py --gpus 8` takes around
+    """One of EIGHT ranks of bench.py's control plane on CPU: bench.plan_shard for both scaling modes, bench.Control.gather_rows
+    (the all_gather of one row per rank), its barrier and the MAX of the elapsed time -- the code paths `bench.py --gpus 8` takes around
     its kernels, here with the oracle standing in for the device on a small shard."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,11 +85,15 @@ def _worker8(rank, world, port, q):
     off, n = sharding.plan_shards(total, world)[rank]
     weak = bench.plan_shard(bench.parse_args(["--gpus", "8", "--gib-per-gpu", "0.125"]), world, rank)
     seg = O.PortOracle().encode_stream(synth.generate("uniform", 42, n, offset=off))
-    rows = bench.gather_rows(dist, world, cpu, [1, int(seg.size), n, 1, 1000 + rank, 2000 + rank])
-    t = torch.tensor([0.25 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
-    q.put((rank, rows, weak, float(t.item()), hashlib.md5(seg.tobytes()).hexdigest(), args.scaling))
+    ctl = bench.Control(dist, world, rank, cpu, True, "gloo", device_sync=lambda: None)      # (no device here: the barrier's GPU sync is a no-op)
+    rows = ctl.gather_rows([1, int(seg.size), n, 1, 1000 + rank, 2000 + rank])
+    slowest = ctl.max_over_ranks(0.25 * (rank + 1))
+    fewest = ctl.min_over_ranks(100 + rank)
+    ctl.barrier()
+    rep = ctl.report()
+    assert rep["backend"] == "gloo" and rep["world"] == world and rep["calls"] == {"barrier": 1, "all_reduce_max": 1, "all_reduce_min": 1, "all_gather": 1}
+    assert fewest == 100
+    q.put((rank, rows, weak, slowest, hashlib.md5(seg.tobytes()).hexdigest(), args.scaling))
     dist.destroy_process_group()
 
 
