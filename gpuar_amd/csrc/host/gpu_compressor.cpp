@@ -33,6 +33,7 @@
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -50,6 +51,7 @@
 
 #include "file_header.hpp"
 #include "gpuar_hip.h"
+#include "input_guard.hpp"
 #include "packet_index.hpp"
 
 namespace gip {
@@ -127,54 +129,78 @@ class MappedInput {
         if (m == MAP_FAILED) return;
         base = static_cast<const uint8_t *>(m);
         size = bytes;
+        guard = InputGuard::watch(base, size);     // a file cut short under the mapping: zeros and a mark instead of SIGBUS (input_guard.hpp)
         (void)::madvise(m, bytes, MADV_SEQUENTIAL);
         state.assign((bytes + kWindow - 1) / kWindow, 0);
         users.assign(state.size(), 0);
         live = 0;
+        frontier = 0;
         if (const char *cap = std::getenv("GPUAR_MAX_WINDOWS")) max_live = std::max<size_t>(1, std::strtoul(cap, nullptr, 10));
+        // (tests only: time for somebody to cut the file short between the mapping and the first read of it)
+        if (const char *hold = std::getenv("GPUAR_TEST_HOLD_AFTER_MAP_MS")) ::usleep(1000u * static_cast<useconds_t>(std::strtoul(hold, nullptr, 10)));
     }
     // makes [at, at + n) DMA-able and counts the caller as a user of its windows until release(at, n);
     // false: this file cannot be registered (the caller reads it with pread instead, and owes no release)
     bool require(uint64_t at, size_t n) {
         if (!base || n == 0) return base != nullptr;
-        std::lock_guard<std::mutex> hold(lock);
+        std::unique_lock<std::mutex> hold(lock);
         if (refused) return false;
         const size_t first = at / kWindow, last = (at + n - 1) / kWindow;
         for (size_t w = first; w <= last; ++w) {
-            if (state[w]) continue;
+            dropped.wait(hold, [&] { return state[w] != kDropping; });      // (a trim of this very window is on its way out: let it finish)
+            if (state[w] == kRegistered) continue;
             const size_t begin = w * kWindow, len = std::min(kWindow, size - begin);
             if (hipHostRegister(const_cast<uint8_t *>(base) + begin, len, hipHostRegisterPortable) != hipSuccess) {
                 (void)hipGetLastError();
                 refused = true;       // e.g. the memlock / userptr limit: from here on everybody reads with pread
                 return false;         // (windows registered so far stay until their users are done)
             }
-            state[w] = 1;
+            state[w] = kRegistered;
             ++live;
         }
         for (size_t w = first; w <= last; ++w) ++users[w];
+        frontier = std::max(frontier, last);
         return true;
     }
     // the copies out of [at, at + n) have completed (the caller synchronised its stream).  Windows nobody uses any more
     // are unregistered, oldest first, once more than `max_live` are registered: the registered (pinned, DMA-mapped)
     // footprint of a job stays at max_live * 256 MiB however large the file is, instead of growing to the whole input.
+    // Never the window the furthest lane has reached (the next chunk starts in it: it would be registered again a moment
+    // later), and never under the lock: hipHostUnregister may synchronise the device, and every other lane's
+    // require() / release() would wait behind it -- the windows to drop are marked under the lock and let go
+    // after it.
     void release(uint64_t at, size_t n) {
         if (!base || n == 0) return;
-        std::lock_guard<std::mutex> hold(lock);
-        for (size_t w = at / kWindow; w <= (at + n - 1) / kWindow; ++w)
-            if (users[w]) --users[w];
-        for (size_t w = 0; w < state.size() && live > max_live; ++w)
-            if (state[w] && !users[w]) {
-                (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
-                state[w] = 0;
-                --live;
-                ++trimmed;
-            }
+        std::vector<size_t> drop;
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            for (size_t w = at / kWindow; w <= (at + n - 1) / kWindow; ++w)
+                if (users[w]) --users[w];
+            for (size_t w = 0; w < state.size() && w < frontier && live > max_live; ++w)
+                if (state[w] == kRegistered && !users[w]) {
+                    state[w] = kDropping;
+                    --live;
+                    drop.push_back(w);
+                }
+        }
+        if (drop.empty()) return;
+        const double t0 = trace_now();
+        for (size_t w : drop) (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            for (size_t w : drop) state[w] = kFree;
+            trimmed += drop.size();
+            trim_seconds += trace_now() - t0;
+        }
+        dropped.notify_all();
     }
     void close() {
         if (warmer.joinable()) warmer.join();
         if (!base) return;
         for (size_t w = 0; w < state.size(); ++w)
-            if (state[w]) (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
+            if (state[w] == kRegistered) (void)hipHostUnregister(const_cast<uint8_t *>(base) + w * kWindow);
+        InputGuard::unwatch(guard);
+        guard = -1;
         ::munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
         state.clear();
@@ -192,11 +218,24 @@ class MappedInput {
         });
     }
     const uint8_t *data() const { return base; }
+    // Is the file still what was mapped?  false once an access to the mapping has faulted (somebody cut the file short:
+    // what was read behind the new end are zeros, input_guard.hpp) or the file's length is no longer the mapped one.
+    // The reference's fread() would have come back short (src/gpu_compressor.cpp:146-150); callers throw its message.
+    bool intact(int fd) const {
+        if (!base) return true;
+        if (InputGuard::cut(guard)) return false;
+        struct stat st;
+        return ::fstat(fd, &st) == 0 && static_cast<uint64_t>(st.st_size) >= size;
+    }
     // a copy must not straddle two registrations: the end of the window `at` lies in
     static size_t windowEnd(uint64_t at) { return (at / kWindow + 1) * kWindow; }
     size_t windowsTrimmed() {
         std::lock_guard<std::mutex> hold(lock);
         return trimmed;
+    }
+    double trimSeconds() {
+        std::lock_guard<std::mutex> hold(lock);
+        return trim_seconds;
     }
     bool wasRefused() {
         std::lock_guard<std::mutex> hold(lock);
@@ -205,15 +244,20 @@ class MappedInput {
 
   private:
     static constexpr size_t kWindow = 256u << 20;
+    static constexpr uint8_t kFree = 0, kRegistered = 1, kDropping = 2;
     std::thread warmer;
     const uint8_t *base = nullptr;
     size_t size = 0;
+    int guard = -1;
     std::mutex lock;
-    std::vector<uint8_t> state;      // per window: registered?
+    std::condition_variable dropped;
+    std::vector<uint8_t> state;      // per window: kFree / kRegistered / kDropping (being unregistered by a release())
     std::vector<uint32_t> users;     // per window: chunks whose copies out of it may still be in flight
     size_t live = 0;                 // registered windows
+    size_t frontier = 0;             // the highest window any lane has required so far: never trimmed
     size_t max_live = 16;            // ... of which at most this many are kept once nobody uses them (4 GiB; GPUAR_MAX_WINDOWS)
     size_t trimmed = 0;
+    double trim_seconds = 0;         // spent inside hipHostUnregister by the trims (GPUAR_TRACE)
     bool refused = false;
 };
 
@@ -736,6 +780,9 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
                             uint32_t flags = 0;
                             const size_t n_stream = b.encodeChunk(n_plain, flags, encode_mode);     // (synchronises the lane's stream)
                             if (from_mapping) mapped.release(at, n_plain);
+                            // the file was cut short (or replaced) under the mapping: what the reference's fread() reports
+                            // (src/gpu_compressor.cpp:146-150)
+                            if (!mapped.intact(in_fd)) throw std::runtime_error("Read input file failed");
                             if (c < 3) trace("compress: kernels of an early chunk done, chunk", static_cast<double>(c));
                             if (flags & GPUAR_STATUS_SLOT_OVERFLOW)
                                 throw std::runtime_error("a packet outgrew its 8704-byte slot (input bytes " + std::to_string(at) + " .. " +
@@ -763,6 +810,7 @@ CompressionInfo GPUCompressor::compress(ProgressMonitor *monitor) {
             trace("compress: lanes done");
             trace(mapped.wasRefused() ? "compress: a window could not be registered: the rest was read with pread" : "compress: every window registered");
             trace("compress: input windows unregistered while the job ran:", static_cast<double>(mapped.windowsTrimmed()));
+            trace("compress: seconds inside hipHostUnregister for that:", mapped.trimSeconds());
             for (size_t g = 0; g < G; ++g)
                 trace(("compress: device " + std::to_string(g) + " coded " + std::to_string(device_bytes[g].load()) + " bytes in " +
                        std::to_string(device_chunks[g].load()) + " chunks of at most " + std::to_string(chunkPackets * kPacket) + " bytes").c_str());
@@ -1085,6 +1133,9 @@ CompressionInfo GPUCompressor::decompress(ProgressMonitor *monitor) {
                             device_chunks[g] += 1;
                             const uint32_t flags = b.decodeChunk(chunk.n_packets);        // (synchronises the lane's stream)
                             if (from_mapping) mapped.release(chunk.begin, n_stream);
+                            // the file was cut short under the mapping (what was read behind its new end are zeros,
+                            // input_guard.hpp): the reference's short fread(), src/gpu_compressor.cpp:299-307
+                            if (!mapped.intact(in_fd)) throw std::runtime_error("Invalid file length");
                             if (flags & GPUAR_STATUS_BAD_PACKET)
                                 throw std::runtime_error("Incorrect file format (malformed packet between file offsets " + std::to_string(chunk.begin) +
                                                          " and " + std::to_string(chunk.end) + ")");

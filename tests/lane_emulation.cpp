@@ -43,7 +43,97 @@ static int encode_slots_with(const uint8_t *in, size_t n_bytes, uint8_t *slots)
     return any_overflow;
 }
 
+// The GPU's store region and rare path, restated for the CPU.  On the device CarryCoderLane::shift_and_store is
+// hand-written gfx950 text that does not call take_top() / leave(): it keeps `held` 16 too high (its shifts look at the low
+// five bits only), stores `cache + over` unconditionally for every lane with a whole dword, finds the lanes for which
+// that was not the whole story with ONE compare against `key` (0xFFFFFFFF, or 0 while dwords of ones wait), and then, for
+// those lanes only: not decided (32 ones, no carry) -> rewind `at`, put the old cache back, count the dword; decided ->
+// let the waiting dwords go out behind what was just stored; key = nff ? 0 : ~0.  This class is that rule statement by
+// statement in plain C++, so that it can be compared with leave() on inputs that keep carrying without a GPU.
+static uint64_t g_rule_undecided = 0, g_rule_filled = 0;      // how often the rare path ran (so a test can tell it was exercised)
+struct DeviceRuleCoder : CarryCoderLane {
+    uint32_t key = 0xFFFFFFFFu;
+    void open_device(uint8_t *uniform_base, uint32_t slot_offset) {
+        open(uniform_base, slot_offset);
+        held = 16u;                                              // what open() does under __HIP_DEVICE_COMPILE__
+    }
+    void store_at(uint32_t word) { store32(base + (at < last ? at : last), bswap32(word)); }      // v_min_u32, v_perm_b32, global_store_dword
+    void step_device(uint32_t cums, Recip rc) {
+        const Ahead a = ahead(cums, rc);
+        const uint64_t sum = ((static_cast<uint64_t>(wh) << 32) | wl) + a.dn;                   // narrow(): w += dn
+        wl = static_cast<uint32_t>(sum), wh = static_cast<uint32_t>(sum >> 32);
+        const uint32_t n = renorm_count(wl & 0xFFFFu, a.wd);
+        held += n;                                               // settled_mask(): v_add_u32, v_cmp_le_u32 48, v_lshlrev_b32
+        const bool full = held >= 48u;
+        range = a.wd << n;
+        const uint64_t w = ((static_cast<uint64_t>(wh) << 32) | wl) << n;                       // shift_and_store(): the 64-bit shift
+        wl = static_cast<uint32_t>(w), wh = static_cast<uint32_t>(w >> 32);
+        if (!full) return;                                       // s_and_saveexec: lanes without a whole dword sit the region out
+        const uint32_t s = held & 31u;                           // (every shift takes `held` itself: the low five bits count)
+        const uint32_t over = wh >> s;
+        const uint32_t sent = cache + over;
+        cache = GPUAR_ALIGNBIT(wh, wl, s);
+        const bool rare = cache >= key;
+        store_at(sent);
+        wl = s ? (wl & ((1u << s) - 1u)) : 0u;                   // v_bfe_u32 wl, 0, held
+        wh = 0;
+        at += 4u;
+        held -= 32u;
+        if (!rare) return;                                       // s_cbranch_scc1 over the rare path
+        const bool undecided = cache == 0xFFFFFFFFu && over == 0u;
+        const uint32_t fill = over == 0u ? 0xFFFFFFFFu : 0u;
+        if (undecided) {
+            at -= 4u;
+            cache = sent;
+            ++nff;
+            ++g_rule_undecided;
+        } else {
+            while (nff) {
+                store_at(fill);
+                at += 4u;
+                --nff;
+                ++g_rule_filled;
+            }
+        }
+        key = nff ? 0u : 0xFFFFFFFFu;
+    }
+    uint32_t finish_device(uint32_t ulen, bool &overflowed) {
+        held -= 16u;                                             // finish() under __HIP_DEVICE_COMPILE__
+        return finish(ulen, overflowed);
+    }
+};
+
+static int encode_slots_device_rule(const uint8_t *in, size_t n_bytes, uint8_t *slots)
+{
+    int any_overflow = 0;
+    const size_t np = (n_bytes + kPacket - 1) / kPacket;
+    std::vector<uint16_t> table(kTreeRows);
+    for (size_t p = 0; p < np; ++p) {
+        const size_t off = p * kPacket;
+        const uint32_t len = static_cast<uint32_t>(n_bytes - off < kPacket ? n_bytes - off : kPacket);
+        TopModeler<1> top;
+        LowModeler<1> low;
+        top.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
+        low.open(reinterpret_cast<uint8_t *>(table.data()), 0, in[off]);
+        DeviceRuleCoder coder;
+        coder.open_device(slots, static_cast<uint32_t>(p * kSlot));
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t next = i + 1 < len ? in[off + i + 1] : 0u;
+            coder.step_device(top.step(in[off + i], 256u + i, next) + low.step(in[off + i], 256u + i, next), kRecip.r[i]);
+        }
+        bool ov;
+        coder.finish_device(len, ov);
+        any_overflow |= ov ? 1 : 0;
+    }
+    return any_overflow;
+}
+
 extern "C" {
+// encode_kernel's coder with the DEVICE's store rule (DeviceRuleCoder above) instead of take_top() + leave()
+int emu_encode_slots_device_rule(const uint8_t *in, size_t n_bytes, uint8_t *slots) { return encode_slots_device_rule(in, n_bytes, slots); }
+// dwords of 32 ones that had to wait (low half) and waiting dwords written out once decided (high half), since the library was loaded
+uint64_t emu_device_rule_rare_events(void) { return (g_rule_filled << 32) | (g_rule_undecided & 0xFFFFFFFFu); }
+
 
 // encode_kernel's coder: the carry form (CarryCoderLane)
 int emu_encode_slots(const uint8_t *in, size_t n_bytes, uint8_t *slots) { return encode_slots_with<CarryCoderLane>(in, n_bytes, slots); }

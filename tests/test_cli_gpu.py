@@ -323,3 +323,31 @@ def test_gpu_cli_empty_input_and_input_without_a_mapping(tmp_path):
     r = subprocess.run([CLI, "d", f"--in={b}", f"--out={back2}", "--batch=64"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr
     assert back2.read_bytes() == data.tobytes()
+
+
+def test_gpu_cli_survives_an_input_cut_short_under_its_mapping(tmp_path):
+    """A MAP_SHARED input truncated while the job runs: accesses behind the new end of the file
+    raise SIGBUS -- in the decoder's header walk, or inside a HIP runtime thread -- and the default action would kill the
+    process.  host/input_guard.hpp turns them into zeros and a mark; the job must end with the reference's message for a
+    short read (src/gpu_compressor.cpp:146-150: "Read input file failed"; decoding: "Invalid file length", :299-307), exit
+    code 1, and an empty output file.  GPUAR_TEST_HOLD_AFTER_MAP_MS makes the race deterministic: the CLI sleeps between
+    mapping its input and reading it, and the file is cut in that window."""
+    import time
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    src, gip, out = tmp_path / "in.dat", tmp_path / "whole.gip", tmp_path / "out.bin"
+    data = synth.text(77, 96 << 20)
+    data.tofile(src)
+    assert run("c", f"--in={src}", f"--out={gip}", "--batch=2048").returncode == 0
+    whole = gip.stat().st_size
+    env = dict(os.environ, GPUAR_TEST_HOLD_AFTER_MAP_MS="3000")
+    for mode, victim, keep, message in (("c", src, 5 << 20, "Read input file failed"), ("d", gip, whole // 3, "Invalid file length")):
+        out.write_bytes(b"stale")
+        p = subprocess.Popen([CLI, mode, f"--in={victim}", f"--out={out}", "--batch=2048"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, env=env)
+        time.sleep(1.0)                                  # the CLI has mapped the file and is holding
+        os.truncate(victim, keep)
+        stdout, stderr = p.communicate(timeout=600)
+        assert p.returncode == 1, (mode, p.returncode, stdout[-500:], stderr[-500:])       # not -SIGBUS
+        assert message in stdout + stderr, (mode, stdout[-500:], stderr[-500:])
+        assert out.stat().st_size == 0

@@ -41,6 +41,10 @@ def emu():
     lib.emu_encode_slots_phased.argtypes = [u8p, C.c_size_t, u8p]
     lib.emu_encode_slots_split.restype = C.c_int
     lib.emu_encode_slots_split.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_encode_slots_device_rule.restype = C.c_int
+    lib.emu_encode_slots_device_rule.argtypes = [u8p, C.c_size_t, u8p]
+    lib.emu_device_rule_rare_events.restype = C.c_uint64
+    lib.emu_device_rule_rare_events.argtypes = []
     lib.emu_decode_stream.restype = C.c_int
     lib.emu_decode_stream.argtypes = [u8p, u64p, C.c_size_t, u8p]
     lib.emu_check_recip.restype = C.c_uint64
@@ -146,6 +150,50 @@ def test_carry_form_coder_on_streams_that_keep_carrying(emu, port_oracle):
         slots, npk, ov = emu_encode(emu, np.ascontiguousarray(data))
         stream, _ = slots_to_stream(slots, npk)
         assert ov == 0 and np.array_equal(stream, port_oracle.encode_stream(data)), trial
+
+
+def carry_heavy_inputs():
+    """Packets whose dwords keep being carried into, and dwords of 32 ones that wait for their verdict (the coder's rare path):
+    midpoint pairs, midpoint pairs with strangers, few-symbol alphabets, long runs (the test below counts how often the rare
+    path really ran)."""
+    rng = np.random.default_rng(31)
+    for trial in range(120):
+        n = int(rng.integers(3000, 8193))
+        kind = trial % 5
+        if kind == 0:
+            data = np.where(rng.random(n) < 0.5, 0x7F, 0x80).astype(np.uint8)
+        elif kind == 1:
+            data = rng.choice(np.array([0x7F, 0x80, 0x00, 0xFF], dtype=np.uint8), n, p=[0.47, 0.47, 0.03, 0.03])
+        elif kind == 2:
+            data = np.full(n, 0x7F, dtype=np.uint8)
+            data[rng.random(n) < float(rng.uniform(0.3, 0.7))] = 0x80
+            data[::int(rng.integers(50, 400))] = int(rng.integers(0, 256))
+        elif kind == 3:
+            data = rng.choice(rng.integers(0, 256, int(rng.integers(2, 5))).astype(np.uint8), n)
+        else:
+            data = np.repeat(rng.integers(0, 256, n // 32 + 1).astype(np.uint8), 32)[:n]
+        yield trial, np.ascontiguousarray(data)
+
+
+def test_device_store_rule_equals_leave_on_streams_that_keep_carrying(emu, port_oracle):
+    """The GPU's store region + rare path (hand-written text in CarryCoderLane::shift_and_store: store `cache + over`, find the
+    rare lanes with one compare against `key`, rewind `at` / let the waiting dwords go, key = nff ? 0 : ~0; `held` kept 16
+    too high) restated in C++ (tests/lane_emulation.cpp, DeviceRuleCoder) against take_top() + leave(), which is what every other CPU
+    test pins against the oracle: the same slots on every golden case -- the packet that owes 2396 bits included -- and on
+    120 packets built to keep carrying.  (the CPU emulation never executed the device's rule.)"""
+    cases = [(c["name"], np.ascontiguousarray(case_input(c))) for c in REFV] + list(carry_heavy_inputs())
+    for name, data in cases:
+        npk = (data.size + 8191) // 8192
+        got = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
+        ov = emu.emu_encode_slots_device_rule(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p))
+        want, _, ov2 = emu_encode(emu, data)
+        assert ov == ov2 == 0 and np.array_equal(got, want), name
+        if not isinstance(name, str) and name % 10 == 0:
+            stream, _ = slots_to_stream(got, npk)
+            assert np.array_equal(stream, port_oracle.encode_stream(data)), name
+    events = emu.emu_device_rule_rare_events()
+    undecided, filled = events & 0xFFFFFFFF, events >> 32
+    assert undecided >= 100 and filled >= 100, (undecided, filled)        # the rare path did run: dwords of ones waited and were let go
 
 
 def test_renormalisation_count_in_one_clz_equals_the_loop(emu):
