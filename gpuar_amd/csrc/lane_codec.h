@@ -45,6 +45,9 @@
 #define GPUAR_XOR1_ADD(a, b) ([](uint32_t a_, uint32_t b_) { uint32_t r_; asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r_) : "v"(a_), "v"(b_)); return r_; }((a), (b)))
 // low 32 bits of (hi:lo) >> (s & 31)
 #define GPUAR_ALIGNBIT(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
+// the 16-bit field of v that starts at bit (off & 31); (a << (s & 31)) + c -- one instruction each
+#define GPUAR_BFE16(v, off) ([](uint32_t v_, uint32_t o_) { uint32_t r_; asm("v_bfe_u32 %0, %1, %2, 16" : "=v"(r_) : "v"(v_), "v"(o_)); return r_; }((v), (off)))
+#define GPUAR_LSHL_ADD(a, s, c) ([](uint32_t a_, uint32_t s_, uint32_t c_) { uint32_t r_; asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r_) : "v"(a_), "v"(s_), "v"(c_)); return r_; }((a), (s), (c)))
 // x as a value the compiler cannot see through (keeps it from re-associating the expression x feeds)
 #define GPUAR_OPAQUE_V(x) ([](uint32_t x_) { asm("" : "+v"(x_)); return x_; }((x)))
 // the load that produces q is issued here, before any later store (no wait is implied)
@@ -65,6 +68,8 @@
 #define GPUAR_MAD24_VS(a, b, c) ((a) * (b) + (c))
 #define GPUAR_OR_WHERE_BIT(a, bit, b, c) (((((a) >> (bit)) & 1u) ? (b) : 0u) | (c))
 #define GPUAR_ALIGNBIT(hi, lo, s) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((s) & 31u))
+#define GPUAR_BFE16(v, off) (((v) >> ((off) & 31u)) & 0xFFFFu)
+#define GPUAR_LSHL_ADD(a, s, c) (((a) << ((s) & 31u)) + (c))
 #define GPUAR_PIN_ORDER(x) ((void)0)
 #define GPUAR_PIN_LOAD(q) ((void)0)
 #define GPUAR_OPAQUE_V(x) (x)
@@ -262,7 +267,8 @@ struct InorderModel {
 template <uint32_t kRowShift, int kFirst, int kDepths, int kHead, bool kTail>
 struct PartialModeler {
     InorderModel<kRowShift> tree;
-    uint32_t root, half0, half1;            // kHead >= 1: depth 0; kHead == 2: depth 1 as well
+    uint32_t root, half0, half1;            // kHead == 1, 2: depth 0; kHead == 2: depth 1 as well
+    uint32_t halves;                        // kHead == 3: depth 1 ALONE in a register, both nodes packed: x < 128 | x >= 128 << 16
     uint32_t left[kDepths];                 // this part's nodes of the NEXT symbol to account
     uint16_t *where[kDepths];
 
@@ -280,6 +286,7 @@ struct PartialModeler {
         }
         root = 128u;
         half0 = half1 = 64u;
+        halves = 64u * 0x10001u;
         prime(first_symbol);
     }
 
@@ -317,6 +324,9 @@ struct PartialModeler {
     }
 
     uint32_t next_tag;                      // row tag of the symbol whose nodes are held in left[] (the next to account)
+#ifdef GPUAR_EXP_TOP_PAD
+    uint32_t pad = 1;
+#endif
 
   private:
     // z: path bits of x | path bits of x + 1, kShift bits up; kAhead: fetch the nodes of the symbol tagged xn behind the stores
@@ -327,13 +337,23 @@ struct PartialModeler {
         // in this part and in the one `onto` came from: the high half is empty and the total can be OR-ed in (two instructions
         // where shift, mask and multiply-add were three)
         if (kTail) acc = GPUAR_OR_WHERE_BIT(z, kShift + 24, total << 16, onto);
-        if (kHead >= 1) {
+        if (kHead == 1 || kHead == 2) {
             const uint32_t pick0 = (z >> (kShift + 7)) & 0x10001u;
             acc = GPUAR_MAD24(root, pick0, acc);
             root = GPUAR_XOR1_ADD(pick0, root) & 0xFFFFu;
         }
-        if (kHead >= 2) {
-            static_assert(kHead < 2 || (kShift == 0 && kAhead), "depth 1 in registers: symbol-based step() only");
+        if (kHead == 3) {
+            // Depth 1 in ONE register (round 5): its two nodes side by side, the one on the path picked by a bit-field extract
+            // whose offset is 16 * (bit 7 of x), the count of x added by a shift-add with the same offset -- eight vector
+            // instructions where the LDS-resident level costs five and two LDS operations (a read and a write that hold a lone
+            // wavefront's issue for ~11 and ~19 cycles, profiles/r05_ldsbw_probe.txt).
+            const uint32_t pick1 = (z >> (kShift + 6)) & 0x10001u;
+            const uint32_t where1 = (z >> (kShift + 3)) & 16u;
+            acc = GPUAR_MAD24(GPUAR_BFE16(halves, where1), pick1, acc);
+            halves = GPUAR_LSHL_ADD(~pick1 & 1u, where1, halves);             // +1 where x goes left
+        }
+        if (kHead == 2) {
+            static_assert(kHead != 2 || (kShift == 0 && kAhead), "depths 0 and 1 in registers: symbol-based step() only");
             const uint32_t x = z & 0xFFu;
             const bool upper_half = x >= 128u;
             const uint32_t pick1 = (z >> 6) & 0x10001u;
@@ -342,11 +362,27 @@ struct PartialModeler {
             half0 += quarter == 0u ? 1u : 0u;
             half1 += quarter == 2u ? 1u : 0u;
         }
+#if defined(GPUAR_EXP_TOP_PAD) && defined(__HIP_DEVICE_COMPILE__)      // (timing experiments only: dummy vector instructions in the top modeler's step)
+        if (kFirst <= 2 && !kTail) {
+#pragma unroll
+            for (int d = 0; d < GPUAR_EXP_TOP_PAD; ++d) asm volatile("v_mad_u32_u24 %0, %0, 1, 0" : "+v"(pad));
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
             const uint32_t pick = (z >> (kShift + 7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
             acc = GPUAR_MAD24(l, pick, acc);
+#if defined(GPUAR_EXP_TOP_ATOMIC) && defined(__HIP_DEVICE_COMPILE__)   // (timing experiments only, WRONG output: one LDS add-with-return per level
+            if (kFirst <= 2 && !kTail) {                               // in the top modeler instead of read + write, at no extra vector instruction)
+                if (kAhead) {
+                    where[k] = tree.node(xn, kFirst + k);
+                    const uint32_t lds_at = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(where[k])) & ~3u;    // (the low half of a generic LDS pointer is the LDS address)
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(left[k]) : "v"(lds_at), "v"(pick) : "memory");
+                }
+                continue;
+            }
+#endif
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
             if (kAhead) {
                 where[k] = tree.node(xn, kFirst + k);
@@ -367,8 +403,16 @@ struct PartialModeler {
 #ifndef GPUAR_TOP_DEPTHS
 #define GPUAR_TOP_DEPTHS 4          // LDS-resident depths the top modeler walks (1 .. GPUAR_TOP_DEPTHS); the low modeler takes the rest
 #endif
+#ifdef GPUAR_EXP_TOP_SKIP_D1        // (timing experiments only, WRONG output: nobody walks depth 1 -- what taking it out of the top modeler's LDS stream could buy at most)
+template <uint32_t kRowShift>
+using TopModeler = PartialModeler<kRowShift, 2, GPUAR_TOP_DEPTHS - 1, 0, false>;
+#elif defined(GPUAR_TOP_D1_REGS)    // depth 1 in a register of the top modeler, depths 2 .. GPUAR_TOP_DEPTHS in LDS
+template <uint32_t kRowShift>
+using TopModeler = PartialModeler<kRowShift, 2, GPUAR_TOP_DEPTHS - 1, 3, false>;
+#else
 template <uint32_t kRowShift>
 using TopModeler = PartialModeler<kRowShift, 1, GPUAR_TOP_DEPTHS, 0, false>;                              // depths 1..
+#endif
 template <uint32_t kRowShift>
 using LowModeler = PartialModeler<kRowShift, 1 + GPUAR_TOP_DEPTHS, 7 - GPUAR_TOP_DEPTHS, 1, true>;        // depth 0 (register), the deepest ones and the x == 255 term
 // the last role of the latency kernel's four-way tree: depth 0 (register), depth 7 and the x == 255 term, whatever the split above
@@ -553,6 +597,17 @@ struct CoderLane {
 // is a placeholder that lands on the packet's header dword, which finish() overwrites.
 // Pinned against the oracle on the CPU like every other lane program (tests/test_lane_emulation.py).
 // ---------------------------------------------------------------------------
+// Cache policy bits of the coder's dword stores (A/B builds -DGPUAR_STORE_POLICY_ID=1, 2, 3: " nt", " sc1", " sc0 sc1"; profiles/r05_encoder_attribution.txt section 3:
+// none of them brings the L2's write-backs nearer to the bytes written, the default is kept)
+#if !defined(GPUAR_STORE_POLICY_ID) || GPUAR_STORE_POLICY_ID == 0
+#define GPUAR_STORE_POLICY ""
+#elif GPUAR_STORE_POLICY_ID == 1
+#define GPUAR_STORE_POLICY " nt"
+#elif GPUAR_STORE_POLICY_ID == 2
+#define GPUAR_STORE_POLICY " sc1"
+#else
+#define GPUAR_STORE_POLICY " sc0 sc1"
+#endif
 struct CarryCoderLane {
     uint32_t wl, wh;     // the window w = wh:wl
     uint32_t range;      // hi - lo + 1  (2^14 < range <= 2^16 between symbols)
@@ -647,7 +702,7 @@ struct CarryCoderLane {
             "v_cmp_ge_u32 %[rare], %[cache], %[key]\n\t"                 /* (bits of lanes that do not store stay 0) */
             "v_min_u32 %[ta], %[at], %[last]\n\t"
             "v_perm_b32 %[tw], 0, %[sent], %[sel]\n\t"
-            "global_store_dword %[ta], %[tw], %[base]\n\t"
+            "global_store_dword %[ta], %[tw], %[base]" GPUAR_STORE_POLICY "\n\t"
             "v_bfe_u32 %[wl], %[wl], 0, %[held]\n\t"                     /* the window keeps what is below the dword that left */
             "v_mov_b32 %[wh], 0\n\t"
             "v_add_u32 %[at], 4, %[at]\n\t"
@@ -672,7 +727,7 @@ struct CarryCoderLane {
             "s_and_b64 exec, exec, vcc\n\t"
             "s_cbranch_execz .Lgpuar_filled_%=\n\t"
             "v_min_u32 %[ta], %[at], %[last]\n\t"
-            "global_store_dword %[ta], %[tw], %[base]\n\t"
+            "global_store_dword %[ta], %[tw], %[base]" GPUAR_STORE_POLICY "\n\t"
             "v_add_u32 %[at], 4, %[at]\n\t"
             "v_add_u32 %[nff], -1, %[nff]\n\t"
             "s_branch .Lgpuar_fill_%=\n\t"
