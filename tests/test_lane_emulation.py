@@ -71,6 +71,26 @@ def emu_small_slots():
     return lib
 
 
+@pytest.fixture(scope="session")
+def emu_d1_regs():
+    """The emulation built with -DGPUAR_TOP_D1_REGS: the top modeler keeps depth 1 of the tree in a register (round 5's A/B
+    build, 1.9 % slower on the GPU and therefore not the default -- profiles/r05_encoder_attribution.txt); as long as the flag
+    is in the tree its output is pinned like the default's."""
+    out_dir = os.path.join(HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liblane_emulation_d1regs.so")
+    srcs = [os.path.join(HERE, "lane_emulation.cpp"), os.path.join(ROOT, "gpuar_amd", "csrc", "lane_codec.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fconstexpr-ops-limit=100000000",
+                               "-fconstexpr-loop-limit=1000000", "-Wno-unknown-pragmas", "-DGPUAR_TOP_D1_REGS",
+                               "-I", os.path.join(ROOT, "include"), "-o", so, srcs[0]])
+    lib = C.CDLL(so)
+    for name in ("emu_encode_slots", "emu_encode_slots_phased"):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [u8p, C.c_size_t, u8p]
+    return lib
+
+
 def emu_encode(lib, data: np.ndarray):
     npk = (data.size + 8191) // 8192
     slots = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
@@ -194,6 +214,18 @@ def test_device_store_rule_equals_leave_on_streams_that_keep_carrying(emu, port_
     events = emu.emu_device_rule_rare_events()
     undecided, filled = events & 0xFFFFFFFF, events >> 32
     assert undecided >= 100 and filled >= 100, (undecided, filled)        # the rare path did run: dwords of ones waited and were let go
+
+
+@pytest.mark.parametrize("c", REFV, ids=lambda c: c["name"])
+def test_depth_one_in_a_register_gives_the_same_slots(emu, emu_d1_regs, c):
+    """PartialModeler with kHead == 3 (depth 1's two nodes packed in one register, picked by a bit-field extract, counted by a
+    shift-add) against the LDS-resident form, straight and in the kernel's phases of eight."""
+    data = np.ascontiguousarray(case_input(c))
+    want, npk, ov = emu_encode(emu, data)
+    for fn in (emu_d1_regs.emu_encode_slots, emu_d1_regs.emu_encode_slots_phased):
+        got = np.zeros(max(npk, 1) * 8704, dtype=np.uint8)
+        assert fn(data.ctypes.data_as(u8p), data.size, got.ctypes.data_as(u8p)) == ov == 0
+        assert np.array_equal(got, want)
 
 
 def test_renormalisation_count_in_one_clz_equals_the_loop(emu):
