@@ -352,8 +352,7 @@ def measure_copy_peak(H, d_src, d_dst, n_bytes, reps=10):
 def annotate_roofs(result, copy_peak, traffic_source=None):
     """Every roofline* object of the line (the by_kind entries' too) gets the roof measured in this run next to the
     datasheet's, and says which of its fields were measured live and which are replayed from a stamped profile record."""
-    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step",
-                "roofline_valu")
+    replayed = ("traffic", "valu_busy", "valu_busy_per_simd", "wait_frac", "valu_insts_per_symbol_step", "lds_insts_per_symbol_step")
     source = traffic_source if traffic_source is not None else result.get("traffic_source")
     for key, r in result.items():
         if key == "by_kind" and isinstance(r, dict):
@@ -365,7 +364,8 @@ def annotate_roofs(result, copy_peak, traffic_source=None):
         if copy_peak:
             r["peak_measured_copy"] = copy_peak["GBps"]
             r["frac_of_measured"] = r["achieved"] / copy_peak["GBps"]
-        r["measured_live"] = "achieved, frac, peak_measured_copy, frac_of_measured (HIP events in this run)"
+        r["measured_live"] = ("achieved, frac, peak_measured_copy, frac_of_measured (HIP events in this run)"
+                              + ("; roofline_valu.shader_clock_measured_MHz (the kernel's own workgroups)" if "roofline_valu" in r else ""))
         have = [k for k in replayed if r.get(k) is not None]
         if have:
             r["counters"] = (f"{', '.join(have)}: replayed from profiles/{source} -- rocprofv3 PMC passes cannot run inside "
@@ -495,17 +495,26 @@ def kernel_symbols(n_packets):
     return {"encode": "encode_small_kernel" if groups <= SMALL_GROUPS else "encode_kernel", "decode": "decode_slots_kernel"}
 
 
-def valu_roof(lane_ops_per_byte, n_bytes, ms, cus=MI355X_CUS, clock_ghz=SHADER_CLOCK_GHZ):
-    """roofline_valu: the vector-issue roof.  achieved = lane-ops per byte (replayed counter) x bytes per launch / launch time."""
+def valu_roof(lane_ops_per_byte, n_bytes, ms, cus=MI355X_CUS, clock_ghz=SHADER_CLOCK_GHZ, measured_mhz=None):
+    """roofline_valu: the vector-issue roof.  achieved = lane-ops per byte (replayed counter) x bytes per launch / launch time;
+    `frac` is against the data sheet's clock, `frac_at_measured_clock` against the shader clock the kernel's own workgroups
+    measured while it ran (s_memtime over s_memrealtime, gpuar_hip_clock_samples) -- under this load the chip does not hold
+    its peak clock, so the second figure says how full the vector pipes really were."""
     peak = cus * 4 * 16 * clock_ghz * 1e9
     achieved = lane_ops_per_byte * n_bytes / (ms * 1e-3)
-    return {"bound": "valu", "lane_ops_per_byte": lane_ops_per_byte, "achieved_lane_ops_per_s": achieved, "peak_lane_ops_per_s": peak,
-            "frac": achieved / peak, "unit": "lane-ops/s",
-            "peak_from": f"{cus} CUs x 4 SIMDs x 16 lanes x {clock_ghz:g} GHz (datasheet peak engine clock, not measured in this run)",
-            "lane_ops_per_byte_from": "SQ_INSTS_VALU per symbol step of a wavefront (64 lanes, 64 bytes), replayed profile record"}
+    r = {"bound": "valu", "lane_ops_per_byte": lane_ops_per_byte, "achieved_lane_ops_per_s": achieved, "peak_lane_ops_per_s": peak,
+         "frac": achieved / peak, "unit": "lane-ops/s",
+         "peak_from": f"{cus} CUs x 4 SIMDs x 16 lanes x {clock_ghz:g} GHz (datasheet peak engine clock)",
+         "lane_ops_per_byte_from": "SQ_INSTS_VALU per symbol step of a wavefront (64 lanes, 64 bytes), replayed profile record"}
+    if measured_mhz:
+        at_measured = cus * 4 * 16 * measured_mhz * 1e6
+        r.update({"shader_clock_measured_MHz": measured_mhz, "peak_lane_ops_per_s_at_measured_clock": at_measured,
+                  "frac_at_measured_clock": achieved / at_measured,
+                  "shader_clock_from": "s_memtime / s_memrealtime x 100 MHz over every 64th workgroup of this kernel's launches in this run"})
+    return r
 
 
-def coder_roof(algo_bytes, n_bytes, ms, counters, kernel, machine=None):
+def coder_roof(algo_bytes, n_bytes, ms, counters, kernel, machine=None, measured_mhz=None):
     """A roofline object of one of the two coder kernels: the HBM figure the contract asks for, the counters replayed
     from the stamped profile record, and -- when that record holds the instruction count -- the roof that binds."""
     a = algo_bytes / (ms * 1e-3) / 1e9
@@ -517,12 +526,14 @@ def coder_roof(algo_bytes, n_bytes, ms, counters, kernel, machine=None):
         if k in t:
             r[k] = t[k]
     if "valu_insts_per_symbol_step" in t:
-        r["roofline_valu"] = valu_roof(t["valu_insts_per_symbol_step"], n_bytes, ms, **(machine or {}))
+        r["roofline_valu"] = valu_roof(t["valu_insts_per_symbol_step"], n_bytes, ms, measured_mhz=measured_mhz, **(machine or {}))
+    elif measured_mhz:
+        r["shader_clock_measured_MHz"] = measured_mhz
     return r
 
 
 def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_rank0, elapsed, enc_ms, dec_ms,
-                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic, machine=None):
+                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic, machine=None, clocks=None):
     """The JSON line, from plain numbers (no GPU objects): the driver's contract fields, the roofline of
     the dominant kernel and what was verified.  enc_ms / dec_ms are rank 0's average launch durations over
     its shard of `shard_bytes` bytes; elapsed is the MAX over ranks of the wall time of args.steps steps."""
@@ -532,9 +543,10 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
     dom = "decode" if dec_ms >= enc_ms else "encode"
     algo_bytes = shard_bytes + c_bytes_rank0
     symbols = kernel_symbols(npk_rank0)
+    clocks = clocks or {}
 
     def roof(ms, which):
-        return coder_roof(algo_bytes, shard_bytes, ms, traffic.get(which), symbols[which], machine)
+        return coder_roof(algo_bytes, shard_bytes, ms, traffic.get(which), symbols[which], machine, clocks.get(which))
 
     if args.scaling == "strong":
         work = (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPU(s), 8192-byte packets, "
@@ -563,12 +575,13 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
     }
 
 
-def kind_result(kind, seed, n, steps, elapsed, enc_ms, dec_ms, c_bytes, roundtrip_equal, oracle_ok, status, traffic, machine=None):
+def kind_result(kind, seed, n, steps, elapsed, enc_ms, dec_ms, c_bytes, roundtrip_equal, oracle_ok, status, traffic, machine=None, clocks=None):
     """One entry of `by_kind`: the same hot path on another of BASELINE.json's single-GPU workloads (configs[2] text,
     configs[4]'s stream kind zipf), timed in the same run as the headline pass and assembled from plain numbers."""
     symbols = kernel_symbols((n + 8191) // 8192)
     algo = n + c_bytes
     dom = "decode" if dec_ms >= enc_ms else "encode"
+    clocks = clocks or {}
     return {
         "workload": f"{kind}({seed}) {n / GIB:g} GiB on 1 GPU, 8192-byte packets",
         "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": n * steps / elapsed / 1e9, "unit": "GB/s",
@@ -576,9 +589,9 @@ def kind_result(kind, seed, n, steps, elapsed, enc_ms, dec_ms, c_bytes, roundtri
         "encode_GBps": n / (enc_ms * 1e-3) / 1e9, "decode_GBps": n / (dec_ms * 1e-3) / 1e9,
         "compression_ratio": (c_bytes + 20) / n, "roundtrip_equal": roundtrip_equal, "oracle_prefix_match": oracle_ok,
         "device_status": status,
-        "roofline": coder_roof(algo, n, dec_ms if dom == "decode" else enc_ms, traffic.get(dom), symbols[dom], machine),
-        "roofline_encode": coder_roof(algo, n, enc_ms, traffic.get("encode"), symbols["encode"], machine),
-        "roofline_decode": coder_roof(algo, n, dec_ms, traffic.get("decode"), symbols["decode"], machine),
+        "roofline": coder_roof(algo, n, dec_ms if dom == "decode" else enc_ms, traffic.get(dom), symbols[dom], machine, clocks.get(dom)),
+        "roofline_encode": coder_roof(algo, n, enc_ms, traffic.get("encode"), symbols["encode"], machine, clocks.get("encode")),
+        "roofline_decode": coder_roof(algo, n, dec_ms, traffic.get("decode"), symbols["decode"], machine, clocks.get("decode")),
         "traffic_source": traffic.get("source"),
     }
 
@@ -629,9 +642,14 @@ def run_pass(args, H, ctl, dev, steps, warmup):
 
     # ---- per-kernel durations (HIP events on the launch stream), untimed region ----
     reps = max(3, min(steps, 10))
+    H.shader_clock_mhz("encode")                             # (reset: only the launches timed below are sampled)
+    H.shader_clock_mhz("decode")
     enc_ms = timed_kernel_ms(encode, reps)
     dec_ms = timed_kernel_ms(decode, reps)
     enc_avg, dec_avg = sum(enc_ms) / len(enc_ms), sum(dec_ms) / len(dec_ms)
+    # the shader clock those very launches ran at, from their own workgroups (None for a launch of the latency kernel,
+    # which does not sample)
+    clocks = {"encode": H.shader_clock_mhz("encode")[0], "decode": H.shader_clock_mhz("decode")[0]}
 
     # ---- correctness of what was just timed ----
     torch.cuda.synchronize()
@@ -640,7 +658,7 @@ def run_pass(args, H, ctl, dev, steps, warmup):
     sample = min(n, 64 << 20)
     md5_in = hashlib.md5(d_in[:sample].cpu().numpy().tobytes()).hexdigest()
     md5_out = hashlib.md5(d_out[:sample].cpu().numpy().tobytes()).hexdigest()
-    return {"n": n, "npk": npk, "elapsed": elapsed, "enc_ms": enc_avg, "dec_ms": dec_avg, "status": status,
+    return {"n": n, "npk": npk, "elapsed": elapsed, "enc_ms": enc_avg, "dec_ms": dec_avg, "status": status, "clocks": clocks,
             "roundtrip_equal": roundtrip_equal, "md5_in": md5_in, "md5_out": md5_out,
             "d_in": d_in, "d_slots": d_slots, "d_out": d_out}
 
@@ -660,7 +678,7 @@ def by_kind_pass(args, H, ctl, dev, kind, seed, machine):
     ok = oracle_prefix_ok(H, P["d_in"], n, npk, d_stream, d_off)
     traffic = load_profiled_traffic(kind, n)
     res = kind_result(kind, seed, n, steps, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes,
-                      bool(P["roundtrip_equal"] and P["md5_in"] == P["md5_out"]), ok, P["status"], traffic, machine)
+                      bool(P["roundtrip_equal"] and P["md5_in"] == P["md5_out"]), ok, P["status"], traffic, machine, P["clocks"])
     del P, d_stream, d_off
     torch.cuda.empty_cache()
     return res
@@ -755,7 +773,8 @@ def main(argv=None):
     if rank == 0:
         traffic = load_profiled_traffic(args.kind, n)
         result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes, c_total,
-                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic, machine)
+                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic, machine, P["clocks"])
+        result["shader_clock_MHz"] = P["clocks"]
         result.update(side)
         for key, rec in (("roofline_compact", "gather"), ("roofline_decode_stream", "decode_stream")):
             if rec in traffic:                      # the PMC passes cover these kernels too (tools/prof_run.py --only all)

@@ -53,6 +53,22 @@ __device__ const MulTable g_mul = MulTable();
 __constant__ DecodeConstTable g_decode = DecodeConstTable();
 __device__ uint32_t g_status = 0;
 __device__ uint32_t g_cu_ticket[2048];      // one arrival counter per CU (XCC, SE, SH, CU), see encode_kernel
+// What the shader clock really was while the two throughput kernels ran (measurement support, gpuar_hip_clock_samples): every
+// 64th workgroup notes how many shader-clock ticks (s_memtime) and how many ticks of the constant 100 MHz clock
+// (s_memrealtime) passed between its start and its end, into a slot of its own -- no atomics, two scalar reads at either
+// end of one wavefront in 64, nothing inside a symbol loop.  Sum of the first / sum of the second x 100 MHz is the clock the
+// vector pipes ran at, which under this load is NOT the 2.4 GHz of the data sheet (bench.py: roofline_valu).
+constexpr uint32_t kClockSlots = 256, kClockEvery = 64;
+__device__ unsigned long long g_clock_samples[2][kClockSlots][4];      // [encode | decode][slot][shader, 100 MHz at the start; the same at the end]
+// (both readings go straight to memory: nothing of this is alive across a symbol loop, so the loops' registers are what they
+// were without it -- tests/test_codeobj_contract.py holds the decoder's step to its instruction budget)
+__device__ __forceinline__ void clock_sample(uint32_t which, size_t group, uint32_t lane, uint32_t end) {      // group: wave-uniform
+    if ((group & (kClockEvery - 1u)) == 0u && lane == 0u) {
+        unsigned long long *slot = g_clock_samples[which][(group / kClockEvery) & (kClockSlots - 1u)] + 2u * end;
+        slot[0] = clock64();
+        slot[1] = wall_clock64();
+    }
+}
 
 // Lane's column in a tree row: lanes l and l+32 share a dword (low/high half),
 // so the 32 lanes of each LDS lane-group hit 32 distinct banks whatever node
@@ -378,6 +394,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
         uint32_t *courier = reinterpret_cast<uint32_t *>(lds.tree + 255u * 128u);
         const uint32_t *table = reinterpret_cast<const uint32_t *>(g_recip.r);
         const uint32_t lane16 = lane & 15u;
+        clock_sample(0u, group, lane, 0u);                     // (this wavefront has the time, and lives as long as the workgroup)
         uint32_t carried = table[lane16];                      // the pairs of phase 0
         for (uint32_t k = 0; k < n_phases + 2u; ++k) {
             // interval k: the coder will work on the symbols of phase k - 1 during interval k + 1 and reads slot (k + 1) & 1
@@ -386,6 +403,7 @@ encode_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__restrict_
             carried = table[next_phase * 16u + lane16];
             lds_barrier();
         }
+        clock_sample(0u, group, lane, 1u);
     } else {
         // ------------------------------- coder -------------------------------
         __builtin_amdgcn_s_setprio(kPrioCoder);
@@ -1255,8 +1273,10 @@ decode_slots_kernel(const uint8_t *__restrict__ slots, uint32_t n_packets, size_
     const size_t group_left = n_bytes - group_at;
     const uint32_t slot_end = (lane + 1u) * kSlot;
     const uint32_t limit_off = group_left < slot_end ? static_cast<uint32_t>(group_left) : slot_end;
+    clock_sample(1u, blockIdx.x, lane, 0u);
     decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_slots, lane * kSlot, limit_off,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live, status);
+    clock_sample(1u, blockIdx.x, lane, 1u);
 }
 
 // Decode from a back-to-back packet stream (the bytes after the 20-byte .gip
@@ -1276,8 +1296,10 @@ decode_stream_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restr
     const uint64_t left = offsets[n_packets] - first;                       // bytes from the base to the end of the stream
     const uint32_t limit_off = left < 0x7FFFFFFFull ? static_cast<uint32_t>(left) : 0x7FFFFFFFu;
     const uint32_t pkt_off = live ? static_cast<uint32_t>(offsets[packet] - first) : 0u;
+    clock_sample(1u, blockIdx.x, lane, 0u);
     decode_wave(reinterpret_cast<uint8_t *>(lds) + 8u * lane, reinterpret_cast<uint8_t *>(lds + kDecodeRecords * kLanes) + 4u * lane, group_stream, pkt_off, limit_off,
                 out + (live ? packet : 0) * static_cast<size_t>(kPacket), live, status);
+    clock_sample(1u, blockIdx.x, lane, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -1664,6 +1686,20 @@ int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *s
     gpuar::copy_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(d_dst), n_quads);
     return check_launch();
+}
+
+int gpuar_hip_clock_samples(int which, uint64_t *ticks, int reset) {
+    if ((which != 0 && which != 1) || !ticks) return GPUAR_ERR_ARGUMENT;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return static_cast<int>(e);
+    const size_t bytes = sizeof(unsigned long long) * gpuar::kClockSlots * 4u, at = static_cast<size_t>(which) * bytes;
+    e = hipMemcpyFromSymbol(ticks, HIP_SYMBOL(gpuar::g_clock_samples), bytes, at);
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (reset) {
+        static const unsigned long long zeros[gpuar::kClockSlots * 4u] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(gpuar::g_clock_samples), zeros, bytes, at);
+    }
+    return e == hipSuccess ? GPUAR_OK : static_cast<int>(e);
 }
 
 // ---- reference-named shims (src/gpuar.h:74,77,78) --------------------------

@@ -22,8 +22,9 @@ EXPORTS = [
     "initConstantRange", "garCompressExecutor", "garDecompressExecutor",
     "gpuar_hip_packet_count", "gpuar_hip_encode", "gpuar_hip_encode_mode", "gpuar_hip_decode", "gpuar_hip_compact",
     "gpuar_hip_decode_stream", "gpuar_hip_status", "gpuar_hip_last_error", "gpuar_hip_error_string",
-    "gpuar_hip_version", "gpuar_hip_abi_version", "gpuar_hip_generate", "gpuar_hip_copy",
+    "gpuar_hip_version", "gpuar_hip_abi_version", "gpuar_hip_generate", "gpuar_hip_copy", "gpuar_hip_clock_samples",
 ]
+CLOCK_SLOTS = 256                    # GPUAR_CLOCK_SLOTS
 ABI_VERSION = 2                      # GPUAR_HIP_ABI_VERSION of the header these bindings were written against
 MODE_ID = {"auto": 0, "throughput": 1, "latency": 2}     # GPUAR_MODE_*
 
@@ -76,6 +77,8 @@ def load() -> C.CDLL:
     lib.gpuar_hip_generate.argtypes = [C.c_int, C.c_uint64, C.c_uint64, sz, vp, vp]
     lib.gpuar_hip_copy.restype = C.c_int
     lib.gpuar_hip_copy.argtypes = [vp, vp, sz, vp]
+    lib.gpuar_hip_clock_samples.restype = C.c_int
+    lib.gpuar_hip_clock_samples.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
     if lib.gpuar_hip_abi_version() != ABI_VERSION:
         raise GpuarError(f"{LIB_PATH} speaks ABI {lib.gpuar_hip_abi_version()}, these bindings {ABI_VERSION}: rebuild the library")
     _lib = lib
@@ -221,3 +224,17 @@ def gip_header(n_uncompressed: int, n_stream: int) -> bytes:
     h[4:12] = int(n_uncompressed).to_bytes(8, "little")
     h[12:20] = int(HEADER_LEN + n_stream).to_bytes(8, "little")
     return bytes(h)
+
+
+def shader_clock_mhz(which: str, reset: bool = True):
+    """The shader clock while the last launches of the throughput encode kernel (which = "encode") or of a decode kernel
+    ("decode") ran, from the samples their workgroups left (gpuar_hip_clock_samples): (MHz, number of samples), or
+    (None, 0) when no sampled workgroup has run to its end since the last reset.  Synchronises the device."""
+    buf = (C.c_uint64 * (4 * CLOCK_SLOTS))()
+    _check(load().gpuar_hip_clock_samples({"encode": 0, "decode": 1}[which], buf, 1 if reset else 0), "gpuar_hip_clock_samples")
+    shader = real = n = 0
+    for i in range(CLOCK_SLOTS):
+        s0, r0, s1, r1 = buf[4 * i:4 * i + 4]
+        if r0 and r1 > r0 and s1 > s0:              # a workgroup that started and ended since the reset
+            shader, real, n = shader + (s1 - s0), real + (r1 - r0), n + 1
+    return (shader / real * 100.0, n) if real else (None, 0)

@@ -173,6 +173,17 @@ int gpuar_hip_generate(int kind, uint64_t seed, uint64_t offset, size_t n, uint8
  * 8 TB/s.  Moves 2 * n_bytes through HBM.  n_bytes < 64 GiB: GPUAR_ERR_ARGUMENT above. */
 int gpuar_hip_copy(const uint8_t *d_src, uint8_t *d_dst, size_t n_bytes, void *stream);
 
+/* Measurement support: the shader clock while the throughput kernels ran.  Every 64th workgroup of encode_kernel
+ * (which = 0) and of the two decode kernels (which = 1) notes, in a slot of its own on the current device, the
+ * shader clock's counter and the constant 100 MHz clock's counter at its start and at its end.
+ * Copies the GPUAR_CLOCK_SLOTS records {shader at start, 100 MHz at start, shader at end, 100 MHz at end} into
+ * ticks[4 * GPUAR_CLOCK_SLOTS] (slots no sampled workgroup has written since the last reset are 0) and, if `reset`,
+ * zeroes them.  Synchronises the device.  sum(shader end - start) / sum(100 MHz end - start) x 100 MHz = the clock
+ * the vector pipes ran at -- under this load not the data sheet's 2.4 GHz, which is why bench.py quotes its
+ * vector-issue roof against both. */
+#define GPUAR_CLOCK_SLOTS 256
+int gpuar_hip_clock_samples(int which, uint64_t *ticks, int reset);
+
 #ifdef __cplusplus
 }
 #endif

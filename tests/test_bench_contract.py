@@ -168,7 +168,16 @@ def test_roofline_valu_says_the_binding_roof_outright():
     assert "roofline_valu" not in stub_line([])["roofline"]
     # another machine shape is stated, not assumed
     m = bench.valu_roof(80.0, GIB, 10.0, cus=128, clock_ghz=2.0)
-    assert m["peak_lane_ops_per_s"] == 128 * 4 * 16 * 2.0e9 and "128 CUs" in m["peak_from"]
+    assert m["peak_lane_ops_per_s"] == 128 * 4 * 16 * 2.0e9 and "128 CUs" in m["peak_from"] and "frac_at_measured_clock" not in m
+    # the clock the kernel's own workgroups measured while it ran: the same achieved figure against THAT roof
+    e = bench.assemble_result(args, 1, 1, n, n, n // 8192, elapsed=0.0447 * args.steps, enc_ms=18.15, dec_ms=26.47, c_bytes_rank0=c,
+                              c_total=c, all_ok=True, md5_in="x", md5_out="x", oracle_ok=True, status=0, traffic=t,
+                              clocks={"encode": 2250.0, "decode": 2350.0})
+    ve, vd = e["roofline_encode"]["roofline_valu"], e["roofline_decode"]["roofline_valu"]
+    assert ve["shader_clock_measured_MHz"] == 2250.0 and vd["shader_clock_measured_MHz"] == 2350.0
+    assert abs(ve["frac_at_measured_clock"] - ve["achieved_lane_ops_per_s"] / (256 * 4 * 16 * 2250.0e6)) < 1e-12
+    assert ve["frac"] < ve["frac_at_measured_clock"] <= 1.01 and abs(ve["frac_at_measured_clock"] - ve["frac"] * 2400 / 2250) < 1e-9
+    assert e["roofline"]["roofline_valu"]["shader_clock_measured_MHz"] == 2350.0          # the dominant kernel is the decoder
 
 
 def test_kernel_symbols_follow_the_launch_size():

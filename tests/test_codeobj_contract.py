@@ -172,10 +172,12 @@ def test_decoder_symbol_step_keeps_its_instruction_budget(code_object, kernel):
     for (valu, ds, waits, vmem, nops, branches), count in middle.items():
         assert valu <= 83 and ds == 5 and waits == 2 and nops == 0, ((valu, ds, waits, vmem, nops, branches), count)
     assert shapes.most_common(1)[0][0][:3] == (82, 5, 2), shapes
-    # the steps in front of a ring phase carry it: two LDS writes, up to three loads, one more wait -- and still no pad
+    # the steps in front of a ring phase carry it: two LDS writes, up to three loads, one more wait; where the compiler's own
+    # scalar bookkeeping for the next run meets the phase's first instruction it may need one wait state (an s_nop 0 in a
+    # slot a scalar instruction would take anyway) -- one, not a pad per lane mask as in the compiler's own schedule of the step
     for (valu, ds, waits, vmem, nops, branches), count in shapes.items():
         if branches == 0:
-            assert nops == 0 and valu <= 90 and ds <= 7 and vmem <= 3, (valu, ds, waits, vmem, nops)
+            assert nops <= (1 if vmem else 0) and valu <= 90 and ds <= 7 and vmem <= 3, (valu, ds, waits, vmem, nops)
 
 
 @pytest.mark.parametrize("kernel", ["decode_slots_kernel", "decode_stream_kernel"])

@@ -120,6 +120,31 @@ def test_device_generators_match_numpy(H):
             assert np.array_equal(got, synth.generate(kind, 9, n, offset=off)), (kind, off, n)
 
 
+def test_shader_clock_samples_of_the_throughput_kernels(H):
+    """gpuar_hip_clock_samples: every 64th workgroup of encode_kernel and of the decode kernels leaves the shader clock's and
+    the 100 MHz clock's counters at its start and its end; their ratio is the clock the kernel ran at (bench.py's
+    roofline_valu at the measured clock).  512 MiB = 1024 groups = 16 sampled workgroups per launch; the result must be a
+    plausible MI355X shader clock, reading resets the samples, and the latency kernel does not sample."""
+    n = 512 << 20
+    d_in = H.generate("uniform", 3, n)
+    npk = H.packet_count(n)
+    H.shader_clock_mhz("encode"), H.shader_clock_mhz("decode")          # reset
+    assert H.shader_clock_mhz("encode") == (None, 0) and H.shader_clock_mhz("decode") == (None, 0)
+    d_slots = H.encode(d_in, mode="throughput")
+    d_out = H.decode(d_slots, npk)
+    enc_mhz, enc_n = H.shader_clock_mhz("encode", reset=False)
+    dec_mhz, dec_n = H.shader_clock_mhz("decode")
+    assert enc_n == 16 and dec_n == 16, (enc_n, dec_n)
+    assert 1000.0 < enc_mhz < 2600.0 and 1000.0 < dec_mhz < 2600.0, (enc_mhz, dec_mhz)
+    assert H.shader_clock_mhz("encode") == (enc_mhz, enc_n)             # (reset=False above left them in place; this read clears them)
+    assert H.shader_clock_mhz("encode") == (None, 0) and H.shader_clock_mhz("decode") == (None, 0)
+    H.encode(d_in[:64 << 20], mode="latency")
+    assert H.shader_clock_mhz("encode") == (None, 0)
+    assert torch.equal(d_out[:n], d_in) and H.status() == 0
+    lib = H.load()
+    assert lib.gpuar_hip_clock_samples(2, (C.c_uint64 * 1024)(), 0) == -2 and lib.gpuar_hip_clock_samples(0, None, 0) == -2
+
+
 def test_device_copy_copies(H):
     """gpuar_hip_copy (bench.py's measured HBM roof) moves exactly the bytes it is given, for sizes around its
     four-quads-per-thread loop and its grid cap."""
