@@ -786,6 +786,8 @@ def main(argv=None):
             "compressed_bytes": [r[1] for r in rows],
         }
 
+    extras_failed = None
+
     def finish_line():
         annotate_roofs(result, copy_peak)
         result["collectives"] = ctl.report()
@@ -802,32 +804,44 @@ def main(argv=None):
             result["scaling_extras"] = f"not finished within {args.extras_timeout} s: left out"
             return finish_line()
         watchdog = Watchdog(args.extras_timeout, line_without_extras, 0 if all_ok else 1)
-        probe = gather_probe(ctl, d_stream, c_bytes)
-        del d_stream, d_off, P
-        torch.cuda.empty_cache()
-        other = argparse.Namespace(**vars(args))
-        other.scaling = "strong" if args.scaling == "weak" else "weak"
-        Q = run_pass(other, H, ctl, dev, max(3, args.steps // 4), 1)
-        q_rows = ctl.gather_rows([int(Q["roundtrip_equal"] and Q["status"] == 0), Q["n"]])
-        if rank == 0:
-            q_total = sum(r[1] for r in q_rows)
-            q_steps = max(3, args.steps // 4)
-            result["gather_probe"] = probe
-            result["other_scaling"] = {
-                "scaling": other.scaling, "value": q_total * q_steps / Q["elapsed"] / 1e9, "unit": "GB/s",
-                "ms_per_step": Q["elapsed"] / q_steps * 1e3, "steps": q_steps, "total_bytes": q_total,
-                "encode_ms_rank0": Q["enc_ms"], "decode_ms_rank0": Q["dec_ms"], "roundtrip_equal": all(r[0] == 1 for r in q_rows),
-                "workload": (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPUs" if other.scaling == "strong"
-                             else f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU"),
-            }
-            all_ok = all_ok and result["other_scaling"]["roundtrip_equal"]
+        try:
+            if os.environ.get("GPUAR_TEST_FAIL_EXTRAS") == str(rank):         # (tests: an extra that raises on this rank)
+                raise RuntimeError("GPUAR_TEST_FAIL_EXTRAS")
+            probe = gather_probe(ctl, d_stream, c_bytes)
+            del d_stream, d_off, P
+            torch.cuda.empty_cache()
+            other = argparse.Namespace(**vars(args))
+            other.scaling = "strong" if args.scaling == "weak" else "weak"
+            Q = run_pass(other, H, ctl, dev, max(3, args.steps // 4), 1)
+            q_rows = ctl.gather_rows([int(Q["roundtrip_equal"] and Q["status"] == 0), Q["n"]])
+            if rank == 0:
+                q_total = sum(r[1] for r in q_rows)
+                q_steps = max(3, args.steps // 4)
+                result["gather_probe"] = probe
+                result["other_scaling"] = {
+                    "scaling": other.scaling, "value": q_total * q_steps / Q["elapsed"] / 1e9, "unit": "GB/s",
+                    "ms_per_step": Q["elapsed"] / q_steps * 1e3, "steps": q_steps, "total_bytes": q_total,
+                    "encode_ms_rank0": Q["enc_ms"], "decode_ms_rank0": Q["dec_ms"], "roundtrip_equal": all(r[0] == 1 for r in q_rows),
+                    "workload": (f"{args.kind}({args.seed}) {args.total_gib:g} GiB in all over {world} GPUs" if other.scaling == "strong"
+                                 else f"{args.kind}({args.seed}) {args.gib_per_gpu:g} GiB per GPU"),
+                }
+                all_ok = all_ok and result["other_scaling"]["roundtrip_equal"]
+            del Q
+        except Exception as e:                                  # noqa: BLE001 -- an extra that RAISES (a transport error, out of memory)
+            # must not cost the run its line either: rank 0 says what failed and goes on to print; the other ranks may be
+            # sitting in a collective this rank has left, so nobody meets the closing barrier (extras_failed below)
+            extras_failed = f"{type(e).__name__}: {e}"[:300]
+            if rank == 0:
+                result["scaling_extras"] = "failed and left out: " + extras_failed
+            else:
+                print(f"bench.py: rank {rank}: scaling extras failed: {extras_failed}", file=sys.stderr, flush=True)
         watchdog.cancel()
-        del Q
     else:
         if args.force_collectives and rank == 0:             # the RCCL preflight: the gather probe's collectives at whatever world this is
             result["gather_probe"] = gather_probe(ctl, d_stream, c_bytes)
         del d_stream, d_off, P
-    torch.cuda.empty_cache()
+    if not extras_failed:
+        torch.cuda.empty_cache()
 
     # ---- BASELINE.json configs[2] and [4]'s stream kinds at the same size, N = 1 only (the other ranks would sit at a barrier) ----
     if rank == 0 and world == 1 and not args.no_by_kind:
@@ -864,6 +878,8 @@ def main(argv=None):
 
     if rank == 0:
         print(finish_line(), flush=True)
+    if extras_failed:                      # some rank may still sit in a collective of the extras: leave without the closing barrier
+        os._exit(0 if all_ok or rank != 0 else 1)
     if ctl.active:
         dist.barrier()
         dist.destroy_process_group()

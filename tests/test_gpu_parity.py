@@ -672,6 +672,26 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["decode_stream_roundtrip_equal"] is True
 
 
+def test_bench_prints_its_line_when_a_scaling_extra_raises(tmp_path):
+    """The N > 1 extras (gather probe, the other scaling mode) must never cost the run its line: when one of them RAISES on
+    rank 0 (a transport error, out of memory) the line of the timed pass is printed with `scaling_extras` saying what failed,
+    and the run ends -- without the closing barrier, which the other rank (still inside the extras' collectives) would never
+    reach -- with exit code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GPUAR_OVERSUBSCRIBE_DEVICES="1", GPUAR_TEST_FAIL_EXTRAS="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gib-per-gpu", "0.125",
+           "--total-gib", "0.25", "--no-cpu-baseline", "--no-small-config", "--extras-timeout", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["roundtrip_equal"] is True and d["value"] > 0
+    assert "GPUAR_TEST_FAIL_EXTRAS" in d["scaling_extras"] and "other_scaling" not in d and "gather_probe" not in d
+
+
 def test_bench_four_rank_dry_run_on_one_gpu(tmp_path):
     """The widest dry run this pool allows: a one-GPU box admits SIX processes on its card at once (a seventh gets the
     whole run killed by its process guard); this test process is one of them and the launcher's agent another, so
