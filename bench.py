@@ -2,7 +2,9 @@
 """bench.py -- encode+decode throughput of the GPUAR packet codec on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
-on rank 0.  For N > 1 there is one process per GPU: either the caller starts
+on rank 0 -- at most 4 KB, numbers only (driver_line()); the full object with
+every roofline, the provenance of each counter and the per-rank arrays goes to
+bench_detail.json next to this file, which the line names.  For N > 1 there is one process per GPU: either the caller starts
 them (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
 RANK/LOCAL_RANK/WORLD_SIZE in the environment) or -- when WORLD_SIZE is not set
 -- this script starts them itself as child processes, before it has touched
@@ -45,6 +47,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 GIB = 1 << 30
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SOURCES = ("gpuar_amd/csrc/gpuar_kernels.hip", "gpuar_amd/csrc/lane_codec.h")
+LINE_LIMIT = 4096                   # bytes: the driver keeps ~8 KB of stdout + stderr; round 5's 22 KB line fell out of it
+DETAIL_FILE = "bench_detail.json"   # everything the line leaves out (prose provenance, every roofline object, per-rank arrays)
 
 
 def parse_args(argv=None):
@@ -70,6 +74,8 @@ def parse_args(argv=None):
                     help="seconds init_process_group and the first barrier may take before the run gives up with one clear line")
     ap.add_argument("--force-collectives", action="store_true",
                     help="route barrier / MAX / all_gather through torch.distributed (RCCL) even at world size 1: the RCCL preflight")
+    ap.add_argument("--detail-file", default=None,
+                    help=f"where the full result object goes (default: {DETAIL_FILE} next to bench.py, and a copy under gpurun_out/ when that exists)")
     return ap.parse_args(argv)
 
 
@@ -119,7 +125,9 @@ class Watchdog:
 
     def __init__(self, seconds, line, code):
         def fire():
-            print(line() if callable(line) else line, file=sys.stderr if code else sys.stdout, flush=True)
+            text = line() if callable(line) else line
+            # stdout carries rank 0's JSON line and nothing else: any other line goes to stderr whatever the exit code
+            print(text, file=sys.stdout if text.startswith("{") else sys.stderr, flush=True)
             os._exit(code)
         self.t = threading.Timer(seconds, fire)
         self.t.daemon = True
@@ -270,7 +278,7 @@ def cpu_baseline(kind, seed, sample_bytes):
     --threads=0` on a file of the same stream, wall time."""
     from gpuar_amd import synth
     from oracle import oracle as O
-    codec = O.best()
+    codec = O.require_best()
     data = synth.generate(kind, seed, sample_bytes)
     t0 = time.perf_counter()
     stream = codec.encode_stream(data)
@@ -281,7 +289,7 @@ def cpu_baseline(kind, seed, sample_bytes):
     enc, dec = data.size / (t1 - t0) / 1e9, data.size / (t2 - t1) / 1e9
     cores, how = usable_cpus()
     res = {
-        "value": data.size / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": codec.kind,
+        "value": data.size / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": codec.kind, "sample_mib": sample_bytes >> 20,
         "sample": f"first {sample_bytes >> 20} MiB of the same {kind}({seed}) stream, encode then decode, 1 thread",
         "encode_GBps": enc, "decode_GBps": dec, "roundtrip_ok": ok,
         "host_cpus_online": os.cpu_count(), "host_cpus_usable": cores, "host_cpus_usable_from": how,
@@ -533,8 +541,8 @@ def coder_roof(algo_bytes, n_bytes, ms, counters, kernel, machine=None, measured
 
 
 def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_rank0, elapsed, enc_ms, dec_ms,
-                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic, machine=None, clocks=None):
-    """The JSON line, from plain numbers (no GPU objects): the driver's contract fields, the roofline of
+                    c_bytes_rank0, c_total, all_ok, md5_in, md5_out, oracle_ok, status, traffic, machine=None, clocks=None, checker=None):
+    """The full result object (bench_detail.json; driver_line() cuts the stdout line out of it), from plain numbers (no GPU objects): the driver's contract fields, the roofline of
     the dominant kernel and what was verified.  enc_ms / dec_ms are rank 0's average launch durations over
     its shard of `shard_bytes` bytes; elapsed is the MAX over ranks of the wall time of args.steps steps."""
     ms_per_step = elapsed / args.steps * 1e3
@@ -568,7 +576,7 @@ def assemble_result(args, world, n_ranks_seen, shard_bytes, total_bytes, npk_ran
         "encode_read_frac_of_hbm_peak": shard_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "compression_ratio": (c_total + 20) / total_bytes,
         "roundtrip_equal": all_ok, "md5_sample_match": md5_in == md5_out, "md5_sample": md5_in,
-        "oracle_prefix_match": oracle_ok, "device_status": status,
+        "oracle_prefix_match": oracle_ok, "checker": checker, "device_status": status,
         "roofline": roof(dec_ms if dom == "decode" else enc_ms, dom),
         "roofline_encode": roof(enc_ms, "encode"), "roofline_decode": roof(dec_ms, "decode"),
         "traffic_source": traffic.get("source"),
@@ -596,14 +604,136 @@ def kind_result(kind, seed, n, steps, elapsed, enc_ms, dec_ms, c_bytes, roundtri
     }
 
 
+def _r(x, digits=5):
+    """A float cut to `digits` significant digits (the line is for reading; the detail file keeps every digit)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def _slim_roof(r):
+    """A roofline object as numbers only: the contract's fields, the roof measured in this run and the vector-issue roof."""
+    if not isinstance(r, dict):
+        return None
+    out = {"bound": r.get("bound"), "achieved": _r(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _r(r.get("frac")),
+           "traffic": r.get("traffic"), "kernel": r.get("kernel")}
+    if r.get("traffic") is not None:
+        out["traffic_from"] = r.get("traffic_from", "replayed")          # one word: "live" (counters of this run) or "replayed"
+    if r.get("peak_measured_copy") is not None:
+        out["peak_measured_copy"] = _r(r["peak_measured_copy"])
+        out["frac_of_measured"] = _r(r.get("frac_of_measured"))
+    v = r.get("roofline_valu")
+    if isinstance(v, dict):
+        out["valu_frac"] = _r(v.get("frac_at_measured_clock", v.get("frac")))
+        out["valu_insts_per_step"] = _r(v.get("lane_ops_per_byte"))
+        if v.get("shader_clock_measured_MHz"):
+            out["clock_MHz"] = _r(v["shader_clock_measured_MHz"])
+    for k in ("valu_busy_per_simd", "wait_frac"):
+        if r.get(k) is not None:
+            out[k] = _r(r[k], 3)
+    return out
+
+
+def driver_line(result, detail_name=DETAIL_FILE):
+    """The ONE stdout line: the contract's fields and the numbers a reader needs, nothing that is prose or repeated
+    (the reference prints a dozen numbers on one screen, src/main.cpp:174-182).  `result` is the full object
+    (assemble_result + everything main() hangs on it); what is not copied here is in the detail file the line names.
+    Bounded by construction: no per-rank arrays, no provenance strings, two roofline objects."""
+    g = result.get
+    line = {
+        "metric": "encode+decode GB/s", "value": _r(g("value"), 6), "unit": g("unit"), "n_gpus": g("n_gpus"), "steps": g("steps"),
+        "warmup": g("warmup"), "ms_per_step": _r(g("ms_per_step"), 6), "higher_is_better": True, "scaling": g("scaling"),
+        "vs_baseline": None, "dtype": "u16", "data": "synthetic", "config": g("config"), "n_ranks_seen": g("n_ranks_seen"),
+        "encode_GBps": _r(g("encode_GBps")), "decode_GBps": _r(g("decode_GBps")), "encode_ms": _r(g("encode_ms")), "decode_ms": _r(g("decode_ms")),
+        "encode_read_frac_of_hbm_peak": _r(g("encode_read_frac_of_hbm_peak")), "compression_ratio": _r(g("compression_ratio"), 7),
+        "roundtrip_equal": g("roundtrip_equal"), "md5_sample_match": g("md5_sample_match"), "oracle_prefix_match": g("oracle_prefix_match"),
+        "checker": g("checker"), "device_status": g("device_status"),
+        "roofline": _slim_roof(g("roofline")), "roofline_encode": _slim_roof(g("roofline_encode")),
+    }
+    for k in ("compact_ms", "encode_plus_compact_ms", "decode_stream_ms"):
+        if g(k) is not None:
+            line[k] = _r(g(k))
+    if isinstance(g("roofline_compact"), dict):
+        line["compact_frac"] = _r(g("roofline_compact").get("frac"))
+    c = g("cpu_baseline")
+    if isinstance(c, dict):
+        cb = {"value": _r(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+              "sample": f"{c.get('sample_mib')} MiB prefix, encode+decode" if c.get("sample_mib") else str(c.get("sample"))[:60],
+              "encode_GBps": _r(c.get("encode_GBps")), "decode_GBps": _r(c.get("decode_GBps")), "roundtrip_ok": c.get("roundtrip_ok")}
+        for sub in ("all_cores", "product_host"):
+            if isinstance(c.get(sub), dict) and "value" in c[sub]:
+                cb[sub] = {"cores": c[sub].get("cores"), "value": _r(c[sub]["value"]), "encode_GBps": _r(c[sub].get("encode_GBps")),
+                           "decode_GBps": _r(c[sub].get("decode_GBps"))}
+        line["cpu_baseline"] = cb
+    if isinstance(g("by_kind"), dict):
+        line["by_kind"] = {
+            kind: {"value": _r(e.get("value")), "encode_ms": _r(e.get("encode_ms")), "decode_ms": _r(e.get("decode_ms")),
+                   "ratio": _r(e.get("compression_ratio"), 6), "frac": _r((e.get("roofline") or {}).get("frac")),
+                   "ok": bool(e.get("roundtrip_equal") and e.get("oracle_prefix_match") and e.get("device_status") == 0)}
+            for kind, e in g("by_kind").items()}
+    s = g("small_config")
+    if isinstance(s, dict):
+        line["small_config"] = {"mib": 64, "encode_GBps": _r(s.get("encode_GBps")), "decode_GBps": _r(s.get("decode_GBps")),
+                                "decode_mode": s.get("decode_mode"),
+                                "md5_match": s.get("stream_md5") == s.get("reference_stream_md5"), "roundtrip_equal": s.get("roundtrip_equal")}
+    if g("n_gpus", 1) > 1 and isinstance(g("per_rank"), dict):
+        line["per_rank"] = {k: _r(v) for k, v in g("per_rank").items() if not isinstance(v, (list, dict))}
+    o = g("other_scaling")
+    if isinstance(o, dict):
+        line["other_scaling"] = {"scaling": o.get("scaling"), "value": _r(o.get("value")), "ms_per_step": _r(o.get("ms_per_step")),
+                                 "roundtrip_equal": o.get("roundtrip_equal")}
+    p = g("gather_probe")
+    if isinstance(p, dict):
+        line["gather_probe"] = {"staged_d2h_ms": _r(p.get("staged_d2h_ms")), "gather_then_d2h_ms": _r(p.get("gather_then_d2h_ms")),
+                                "cheaper": p.get("cheaper"), "rccl": str(p.get("transport", "")).startswith("RCCL")}
+    if g("scaling_extras"):
+        line["scaling_extras"] = str(g("scaling_extras"))[:160]
+    col = g("collectives")
+    if isinstance(col, dict):
+        line["collectives"] = {"backend": col.get("backend"), "calls": sum((col.get("calls") or {}).values())}
+    line["detail"] = detail_name
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:            # cannot happen with the fields above; if it ever does, the contract's fields survive
+        for k in ("collectives", "gather_probe", "other_scaling", "per_rank", "small_config", "by_kind", "compact_frac"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
+def write_detail(result, path=None, root=ROOT):
+    """The full object: to `path` (--detail-file) or, by default, next to bench.py and -- when that directory exists -- under
+    gpurun_out/, so a gpurun call brings it home.  Returns the name the line quotes, or None when nothing could be written
+    (a read-only tree): the line still prints."""
+    targets = [path] if path else [os.path.join(root, DETAIL_FILE)] + (
+        [os.path.join(root, "gpurun_out", DETAIL_FILE)] if os.path.isdir(os.path.join(root, "gpurun_out")) else [])
+    written = None
+    for t in targets:
+        try:
+            with open(t + ".tmp", "w") as f:
+                json.dump(result, f, indent=1)
+            os.replace(t + ".tmp", t)
+            written = written or (path if path else DETAIL_FILE)
+        except OSError:
+            pass
+    return written
+
+
 def oracle_prefix_ok(H, d_in, n, npk, d_stream, d_off, packets=64):
     """The first `packets` packets of the compacted stream against the oracle on the same bytes (checker only, untimed)."""
     from oracle import oracle as O
     k = min(packets, npk)
     host = d_in[:min(n, k * H.PACKET)].cpu().numpy()
-    want = O.best().encode_stream(host)
+    want = O.require_best().encode_stream(host)
     got = d_stream[:int(d_off[k].item())].cpu().numpy()
     return bool(got.size == want.size and (got == want).all())
+
+
+def checker_kind():
+    """Which oracle the prefix checks of this run compared with: "reference" (oracle/_ref: the reference's own codec) or "port"."""
+    from oracle import oracle as O
+    return O.require_best().kind              # raises where the pinned reference binary is expected and missing
 
 
 def run_pass(args, H, ctl, dev, steps, warmup):
@@ -773,7 +903,7 @@ def main(argv=None):
     if rank == 0:
         traffic = load_profiled_traffic(args.kind, n)
         result = assemble_result(args, world, n_ranks_seen, n, total_bytes, npk, P["elapsed"], P["enc_ms"], P["dec_ms"], c_bytes, c_total,
-                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic, machine, P["clocks"])
+                                 all_ok, P["md5_in"], P["md5_out"], oracle_ok, P["status"], traffic, machine, P["clocks"], checker=checker_kind())
         result["shader_clock_MHz"] = P["clocks"]
         result.update(side)
         for key, rec in (("roofline_compact", "gather"), ("roofline_decode_stream", "decode_stream")):
@@ -789,9 +919,10 @@ def main(argv=None):
     extras_failed = None
 
     def finish_line():
+        """The stdout line (<= LINE_LIMIT bytes); the full object goes to bench_detail.json first."""
         annotate_roofs(result, copy_peak)
         result["collectives"] = ctl.report()
-        return json.dumps(result)
+        return driver_line(result, write_detail(result, args.detail_file))
 
     # ---- N > 1: the OTHER scaling mode in the same run (configs[3] strong: 8 GiB over N; configs[4] weak: 8 GiB each),
     #      and the measurement behind "RCCL only if a gather is measurably cheaper than staged hipMemcpyAsync" ----
@@ -837,7 +968,7 @@ def main(argv=None):
                 print(f"bench.py: rank {rank}: scaling extras failed: {extras_failed}", file=sys.stderr, flush=True)
         watchdog.cancel()
     else:
-        if args.force_collectives and rank == 0:             # the RCCL preflight: the gather probe's collectives at whatever world this is
+        if args.force_collectives and world == 1:            # the RCCL preflight (a world of one: the probe's collectives have no peer to miss)
             result["gather_probe"] = gather_probe(ctl, d_stream, c_bytes)
         del d_stream, d_off, P
     if not extras_failed:

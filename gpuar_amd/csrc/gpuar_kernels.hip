@@ -63,8 +63,10 @@ __device__ unsigned long long g_clock_samples[2][kClockSlots][4];      // [encod
 // (both readings go straight to memory: nothing of this is alive across a symbol loop, so the loops' registers are what they
 // were without it -- tests/test_codeobj_contract.py holds the decoder's step to its instruction budget)
 __device__ __forceinline__ void clock_sample(uint32_t which, size_t group, uint32_t lane, uint32_t end) {      // group: wave-uniform
-    if ((group & (kClockEvery - 1u)) == 0u && lane == 0u) {
-        unsigned long long *slot = g_clock_samples[which][(group / kClockEvery) & (kClockSlots - 1u)] + 2u * end;
+    // only the first kClockSlots x kClockEvery groups of a launch (8 GiB) sample: beyond them slots would be shared, and a slot
+    // holding the start of one workgroup and the end of another -- possibly on XCDs whose counters differ -- is no measurement
+    if ((group & (kClockEvery - 1u)) == 0u && group < size_t(kClockSlots) * kClockEvery && lane == 0u) {
+        unsigned long long *slot = g_clock_samples[which][group / kClockEvery] + 2u * end;
         slot[0] = clock64();
         slot[1] = wall_clock64();
     }

@@ -136,8 +136,13 @@ class MappedInput {
         live = 0;
         frontier = 0;
         if (const char *cap = std::getenv("GPUAR_MAX_WINDOWS")) max_live = std::max<size_t>(1, std::strtoul(cap, nullptr, 10));
-        // (tests only: time for somebody to cut the file short between the mapping and the first read of it)
-        if (const char *hold = std::getenv("GPUAR_TEST_HOLD_AFTER_MAP_MS")) ::usleep(1000u * static_cast<useconds_t>(std::strtoul(hold, nullptr, 10)));
+        // (tests only: time for somebody to cut the file short between the mapping and the first read of it;
+        // and says on stderr that it is there, so the test need not guess how long start-up took)
+        if (const char *hold = std::getenv("GPUAR_TEST_HOLD_AFTER_MAP_MS")) {
+            std::fprintf(stderr, "[gpuar] input mapped\n");
+            std::fflush(stderr);
+            ::usleep(1000u * static_cast<useconds_t>(std::strtoul(hold, nullptr, 10)));
+        }
     }
     // makes [at, at + n) DMA-able and counts the caller as a user of its windows until release(at, n);
     // false: this file cannot be registered (the caller reads it with pread instead, and owes no release)
@@ -146,19 +151,24 @@ class MappedInput {
         std::unique_lock<std::mutex> hold(lock);
         if (refused) return false;
         const size_t first = at / kWindow, last = (at + n - 1) / kWindow;
+        // The caller counts as a user of EVERY window of its range before anything below can wait: dropped.wait() lets go of
+        // the lock, and a release() on another lane only ever marks windows with no users -- so a window of this range that is
+        // already registered cannot be taken away while a later one is waited for (with the count taken after the
+        // loop, a chunk straddling a window boundary could be handed a window that was being unregistered).
+        for (size_t w = first; w <= last; ++w) ++users[w];
         for (size_t w = first; w <= last; ++w) {
             dropped.wait(hold, [&] { return state[w] != kDropping; });      // (a trim of this very window is on its way out: let it finish)
             if (state[w] == kRegistered) continue;
             const size_t begin = w * kWindow, len = std::min(kWindow, size - begin);
-            if (hipHostRegister(const_cast<uint8_t *>(base) + begin, len, hipHostRegisterPortable) != hipSuccess) {
-                (void)hipGetLastError();
+            if (refused || hipHostRegister(const_cast<uint8_t *>(base) + begin, len, hipHostRegisterPortable) != hipSuccess) {
+                if (!refused) (void)hipGetLastError();
                 refused = true;       // e.g. the memlock / userptr limit: from here on everybody reads with pread
+                for (size_t u = first; u <= last; ++u) --users[u];            // (the caller owes no release)
                 return false;         // (windows registered so far stay until their users are done)
             }
             state[w] = kRegistered;
             ++live;
         }
-        for (size_t w = first; w <= last; ++w) ++users[w];
         frontier = std::max(frontier, last);
         return true;
     }
@@ -177,7 +187,7 @@ class MappedInput {
             for (size_t w = at / kWindow; w <= (at + n - 1) / kWindow; ++w)
                 if (users[w]) --users[w];
             for (size_t w = 0; w < state.size() && w < frontier && live > max_live; ++w)
-                if (state[w] == kRegistered && !users[w]) {
+                if (state[w] == kRegistered && !users[w]) {      // (no users AT MARKING TIME, and require() counts before it waits)
                     state[w] = kDropping;
                     --live;
                     drop.push_back(w);

@@ -64,11 +64,20 @@ class InputGuard {
         static struct sigaction old;
         return old;
     }
+    static std::atomic<uintptr_t> &pageSize() {
+        static std::atomic<uintptr_t> bytes{4096};
+        return bytes;
+    }
     static void install() {
         static std::atomic<bool> done{false};
         bool expect = false;
         if (!done.compare_exchange_strong(expect, true)) return;
         (void)slots();
+        (void)previous();
+        // everything the handler touches exists before it can run: no function-local static is first initialised (and
+        // sysconf is not called) inside the signal handler
+        const long p = ::sysconf(_SC_PAGESIZE);
+        if (p > 0) pageSize().store(static_cast<uintptr_t>(p));
         struct sigaction act;
         act.sa_sigaction = &InputGuard::onSigbus;
         sigemptyset(&act.sa_mask);
@@ -78,7 +87,7 @@ class InputGuard {
     // async-signal-safe: atomics, mmap and sigaction only
     static void onSigbus(int sig, siginfo_t *info, void *context) {
         const uintptr_t addr = reinterpret_cast<uintptr_t>(info->si_addr);
-        static const uintptr_t page = static_cast<uintptr_t>(::sysconf(_SC_PAGESIZE));
+        const uintptr_t page = pageSize().load();
         for (int s = 0; s < kSlots; ++s) {
             const uintptr_t base = slots()[s].base.load();
             const size_t size = slots()[s].size.load();

@@ -345,6 +345,30 @@ def best():
     return ReferenceOracle() if have_reference() else PortOracle()
 
 
+def expected_kind() -> str:
+    """Which checker a box is EXPECTED to have.  tests/golden/ref_vectors.json is committed and records the sha256 of the
+    oracle/_ref/libgpuar_ref.so that made it (oracle/build_ref.sh: the reference's own codec); that binary travels with
+    every push to a GPU box.  So wherever the pin exists the checker must be "reference" -- a box without the binary would
+    otherwise turn "bit-exact vs the reference" into "bit-exact vs our port" without a red test.  GPUAR_ALLOW_PORT_CHECKER=1
+    says out loud that the port is acceptable (a checkout that never had /root/reference)."""
+    if os.environ.get("GPUAR_ALLOW_PORT_CHECKER") == "1" or pinned_checker_sha256() is None:
+        return "port"
+    return "reference"
+
+
+def require_best():
+    """best(), or an error when it is weaker than expected_kind() says this box must have."""
+    want = expected_kind()
+    if want == "reference" and not have_reference():
+        raise CheckerMismatch(f"{REF_LIB_PATH} is missing but tests/golden/ref_vectors.json pins it: the parity claims of this box would "
+                              "be against the port, not the reference's codec.  Build it where /root/reference exists (oracle/build_ref.sh) "
+                              "and push it, or set GPUAR_ALLOW_PORT_CHECKER=1 to accept the port knowingly.")
+    codec = best()
+    if want == "reference" and codec.kind != "reference":
+        raise CheckerMismatch(f"checker is {codec.kind!r}, expected 'reference'")
+    return codec
+
+
 # -- container (20-byte header) as the reference writes it -------------------
 # src/file_header.hpp:19-36,61-72; zeros where the reference leaves stack garbage.
 def gip_header(n_uncompressed: int, n_stream: int) -> bytes:

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import bench  # noqa: E402
+import bench_stub  # noqa: E402
 
 GIB = 1 << 30
 
@@ -36,7 +37,8 @@ def test_json_line_has_the_contract_fields_and_consistent_arithmetic():
     assert abs(d["value"] - 8 * GIB / 0.0709 / 1e9) < 1e-6            # value = bytes of all ranks / time
     r = d["roofline"]
     # dominant kernel = the slower one; achieved = (N + C) / its launch duration; frac = achieved / 8 TB/s
-    assert r["kernel"] == "decode_slots_kernel" and r["bound"] == "hbm"      # the symbol rocprofv3 lists, not a nickname and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the kernel is named by the symbol rocprofv3 lists, not by a nickname
+    assert r["kernel"] == "decode_slots_kernel" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["algorithmic_bytes_per_launch"] == 8 * GIB + 8658985568
     assert abs(r["achieved"] - (8 * GIB + 8658985568) / 46.3e-3 / 1e9) < 1e-6
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
@@ -250,3 +252,65 @@ def test_control_plane_without_a_process_group_is_plain_python():
     assert c.max_over_ranks(1.5) == 1.5 and c.min_over_ranks(7) == 7 and c.gather_rows([1, 2, 3]) == [[1, 2, 3]]
     rep = c.report()
     assert rep["through_torch_distributed"] is False and rep["backend"] is None and sum(rep["calls"].values()) == 0
+
+
+def test_the_stdout_line_fits_the_drivers_capture_at_world_1_and_world_8(tmp_path):
+    """the round's number was lost because the line (22 KB) fell out of the driver's ~8 KB tail.  The line is
+    now cut out of the full object by driver_line(): <= 4096 bytes with every extra a run can hang on it, at N = 1 (by_kind,
+    small_config, cpu_baseline) and at N = 8 in both scaling modes (per-rank figures, the other scaling mode, the gather
+    probe); numbers only; the full object goes to the detail file the line names."""
+    for world, scaling in ((1, "weak"), (8, "weak"), (8, "strong"), (2, "weak"), (4, "strong")):
+        full = bench_stub.full_result(world, scaling)
+        path = str(tmp_path / f"detail_{world}_{scaling}.json")
+        name = bench.write_detail(full, path)
+        assert name == path
+        text = bench.driver_line(full, name)
+        d = bench_stub.check_line(text, world)
+        assert len(json.dumps(full)) > 2 * len(text)                   # (the stub really is the long object)
+        assert d["scaling"] == scaling and d["detail"] == path and d["checker"] == "reference"
+        assert json.load(open(path)) == json.loads(json.dumps(full))   # nothing is lost: the detail file holds the whole object
+        assert d["roofline"]["kernel"] == "decode_slots_kernel" and d["roofline"]["traffic"] == 18660000000.0
+        assert d["roofline"]["traffic_from"] == "replayed"
+        assert d["roofline_encode"]["kernel"] == "encode_kernel"
+        if world == 1:
+            assert set(d["by_kind"]) == {"text", "zipf"} and d["by_kind"]["text"]["ok"] is True and 0.67 < d["by_kind"]["text"]["ratio"] < 0.68
+            assert d["small_config"]["md5_match"] is True and d["small_config"]["encode_GBps"] > d["small_config"]["decode_GBps"] > 0
+            c = d["cpu_baseline"]
+            assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "GB/s" and "16 MiB" in c["sample"]
+            assert c["all_cores"]["cores"] == 16 and c["product_host"]["value"] > c["all_cores"]["value"]
+            assert "per_rank" not in d and "other_scaling" not in d
+        else:
+            assert d["n_ranks_seen"] == world and "by_kind" not in d and "cpu_baseline" not in d
+            assert d["per_rank"]["encode_ms_min"] <= d["per_rank"]["encode_ms_max"] and "compressed_bytes" not in d["per_rank"]
+            assert d["other_scaling"]["scaling"] != scaling and d["gather_probe"]["cheaper"] == "staged hipMemcpyAsync" and d["gather_probe"]["rccl"] is True
+            assert d["collectives"] == {"backend": "nccl", "calls": 43}
+    # the driver's view: the tail of stdout + stderr, with launcher chatter before the line and warnings behind it
+    text = bench.driver_line(bench_stub.full_result(8, "weak"))
+    stdout = "W1004 torch.distributed.run: setting OMP_NUM_THREADS=1\n" * 40 + text + "\n"
+    stderr = "/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n" * 8
+    got = bench_stub.line_from_driver_tail(stdout, stderr)
+    assert got == json.loads(text)
+
+
+def test_a_line_that_would_not_fit_sheds_its_extras_not_its_contract():
+    full = bench_stub.full_result(1, "weak")
+    full["by_kind"] = {f"kind{k}": dict(full["by_kind"]["text"]) for k in range(60)}      # (no run makes this; the guard is for the unforeseen)
+    text = bench.driver_line(full)
+    assert len(text) <= bench.LINE_LIMIT
+    d = json.loads(text)
+    assert "by_kind" not in d and d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" in d
+
+
+def test_watchdog_keeps_stdout_for_the_json_line_only():
+    """a rank other than 0 whose extras timer fires must not put a non-JSON line on stdout (the one-line contract)."""
+    import subprocess
+    code = ("import bench, time\n"
+            "w = bench.Watchdog(0.2, lambda: 'bench.py: rank 3: scaling extras not finished', 0)\n"
+            "time.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and r.stdout == "" and "rank 3" in r.stderr
+    code = ("import bench, time\n"
+            "w = bench.Watchdog(0.2, lambda: '{\"metric\": 1}', 1)\n"
+            "time.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=20)
+    assert r.returncode == 1 and r.stdout.strip() == '{"metric": 1}'

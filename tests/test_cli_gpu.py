@@ -161,14 +161,14 @@ def test_gpu_cli_file_over_4gib(tmp_path):
     assert int.from_bytes(blob[12:20], "little") == len(blob)
     npk = (n + 8191) // 8192
     from oracle import oracle as O
-    zero_pkt = O.best().encode_packet(bytes(8192))
+    zero_pkt = O.require_best().encode_packet(bytes(8192))
     assert len(zero_pkt) == 210
     # first packets = the text island, then zero packets
-    want_head = O.best().encode_stream(islands[0]).tobytes()
+    want_head = O.require_best().encode_stream(islands[0]).tobytes()
     assert blob[20:20 + len(want_head)] == want_head
     assert blob[20 + len(want_head):20 + len(want_head) + 210] == zero_pkt
     # the tail island (last two packets, the very last one short) closes the file
-    want_tail = O.best().encode_stream(islands[n - 4321 - 8192]).tobytes()
+    want_tail = O.require_best().encode_stream(islands[n - 4321 - 8192]).tobytes()
     assert blob[-len(want_tail):] == want_tail
     assert len(blob) > 20 + (npk - 8) * 210
     # The mapped input is registered for DMA in 256 MiB windows; windows nobody copies from any more are unregistered
@@ -340,12 +340,15 @@ def test_gpu_cli_survives_an_input_cut_short_under_its_mapping(tmp_path):
     data.tofile(src)
     assert run("c", f"--in={src}", f"--out={gip}", "--batch=2048").returncode == 0
     whole = gip.stat().st_size
-    env = dict(os.environ, GPUAR_TEST_HOLD_AFTER_MAP_MS="3000")
+    env = dict(os.environ, GPUAR_TEST_HOLD_AFTER_MAP_MS="1500")
     for mode, victim, keep, message in (("c", src, 5 << 20, "Read input file failed"), ("d", gip, whole // 3, "Invalid file length")):
         out.write_bytes(b"stale")
         p = subprocess.Popen([CLI, mode, f"--in={victim}", f"--out={out}", "--batch=2048"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              text=True, env=env)
-        time.sleep(1.0)                                  # the CLI has mapped the file and is holding
+        # the CLI says "[gpuar] input mapped" once it has sized and mapped the file, then holds: cut the file THEN, however long
+        # ROCm's start-up took on this box (a fixed sleep raced it)
+        first = p.stderr.readline()
+        assert "input mapped" in first, (mode, first)
         os.truncate(victim, keep)
         stdout, stderr = p.communicate(timeout=600)
         assert p.returncode == 1, (mode, p.returncode, stdout[-500:], stderr[-500:])       # not -SIGBUS

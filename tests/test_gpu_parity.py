@@ -31,8 +31,21 @@ def H():
 
 @pytest.fixture(scope="module")
 def oracle():
+    """The checker of every parity test below -- and it must be the one this box is expected to have: the reference's own codec
+    (oracle/_ref) wherever the committed golden vectors pin its binary.  A box that lacks it fails HERE, red, instead of
+    quietly comparing the kernels with our own port."""
     from oracle import oracle as O
-    return O.best()
+    codec = O.require_best()
+    assert codec.kind == O.expected_kind()
+    return codec
+
+
+def test_the_checker_on_this_box_is_the_reference_codec(oracle):
+    from oracle import oracle as O
+    if os.environ.get("GPUAR_ALLOW_PORT_CHECKER") == "1":
+        pytest.skip("GPUAR_ALLOW_PORT_CHECKER=1: the port was accepted knowingly")
+    assert O.pinned_checker_sha256(), "tests/golden/ref_vectors.json lost its checker pin"
+    assert oracle.kind == "reference" and O.file_sha256(O.REF_LIB_PATH) == O.pinned_checker_sha256()
 
 
 @pytest.fixture(params=["latency", "throughput"])
@@ -361,7 +374,7 @@ def test_round_trip_properties_at_scale(H):
     from oracle import oracle as O
     p0 = npk // 2
     host = d_in[p0 * 8192:(p0 + 32) * 8192].cpu().numpy()
-    want = O.best().encode_stream(host)
+    want = O.require_best().encode_stream(host)
     got = d_stream[int(d_off[p0].item()):int(d_off[p0 + 32].item())].cpu().numpy()
     assert np.array_equal(got, want)
 
@@ -609,6 +622,20 @@ def test_slot_overflow_is_flagged_and_contained_on_the_device(small_slot_lib, or
         assert np.array_equal(s0[4:slot - 8], want[4:slot - 8]), p
 
 
+def bench_line_and_detail(r, tmp_path):
+    """(stdout line, full object) of a finished bench.py child.  The line is read the way the DRIVER reads it -- out of the last
+    6000 bytes of stdout + "---- stderr ----" + stderr -- and held to its size rule; the deep fields come from the detail file
+    the line names (the run was given --detail-file under tmp_path)."""
+    import bench_stub
+    d = bench_stub.line_from_driver_tail(r.stdout, r.stderr)
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) >= 1
+    assert [l for l in r.stdout.splitlines() if l.startswith("{")][-1:] == [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1:]
+    assert d["detail"] == str(tmp_path / "detail.json"), d["detail"]
+    full = json.load(open(d["detail"]))
+    assert abs(full["value"] - d["value"]) <= 1e-5 * full["value"] and full["roofline"]["kernel"] == d["roofline"]["kernel"]
+    return d, full
+
+
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     """bench.py --gpus 2 through torch.distributed.run, both ranks on this box's one GPU (gloo control
     plane, GPUAR_OVERSUBSCRIBE_DEVICES=1): rank r codes bytes [r*B, (r+1)*B) of the stream, the JSON line
@@ -624,11 +651,10 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--gib-per-gpu", "0.25", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config"]
+           "--gib-per-gpu", "0.25", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    d, _ = bench_line_and_detail(r, tmp_path)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
     assert abs(d["compression_ratio"] - 1.00804) < 1e-3
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
@@ -643,20 +669,25 @@ def _self_launched_bench(extra, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--no-small-config", *extra]
+           "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json"), *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    return json.loads(lines[0])
+    return bench_line_and_detail(r, tmp_path)
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
-    d = _self_launched_bench(["--gib-per-gpu", "0.25", "--total-gib", "0.5"], tmp_path)
+    line, d = _self_launched_bench(["--gib-per-gpu", "0.25", "--total-gib", "0.5"], tmp_path)
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak"
     assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True and d["device_status"] == 0
     assert abs(d["compression_ratio"] - 1.00804) < 1e-3
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 0.25 * 1.073741824) < 1e-6    # both ranks' bytes over the time
+    # the stdout line: the same run in numbers only (per-rank min/max, no arrays), with the extras of a world of N in short form
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["roundtrip_equal"] is True and line["checker"] == d["checker"]
+    assert set(line["per_rank"]) == {"encode_ms_min", "encode_ms_max", "decode_ms_min", "decode_ms_max"}
+    assert line["other_scaling"]["scaling"] == "strong" and line["other_scaling"]["roundtrip_equal"] is True
+    assert line["gather_probe"]["cheaper"] == d["gather_probe"]["cheaper"] and line["gather_probe"]["rccl"] is False
     # what an 8-GPU run must carry in the same line: per-rank kernel times, the other scaling mode,
     # and the staged-copy vs gather measurement
     pr = d["per_rank"]
@@ -683,11 +714,12 @@ def test_bench_prints_its_line_when_a_scaling_extra_raises(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(GPUAR_OVERSUBSCRIBE_DEVICES="1", GPUAR_TEST_FAIL_EXTRAS="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gib-per-gpu", "0.125",
-           "--total-gib", "0.25", "--no-cpu-baseline", "--no-small-config", "--extras-timeout", "20"]
+           "--total-gib", "0.25", "--no-cpu-baseline", "--no-small-config", "--extras-timeout", "20", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
-    d = json.loads(lines[0])
+    d, full = bench_line_and_detail(r, tmp_path)
+    assert "GPUAR_TEST_FAIL_EXTRAS" in full["scaling_extras"] and "other_scaling" not in full
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["roundtrip_equal"] is True and d["value"] > 0
     assert "GPUAR_TEST_FAIL_EXTRAS" in d["scaling_extras"] and "other_scaling" not in d and "gather_probe" not in d
 
@@ -705,10 +737,11 @@ def test_bench_four_rank_dry_run_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--gib-per-gpu", "0.125", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config"]
+           "--gib-per-gpu", "0.125", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    line, d = bench_line_and_detail(r, tmp_path)
+    assert line["n_gpus"] == world and line["n_ranks_seen"] == world and "compressed_bytes" not in line["per_rank"]
     assert d["n_gpus"] == world and d["n_ranks_seen"] == world and d["scaling"] == "weak"
     assert d["roundtrip_equal"] is True and d["device_status"] == 0
     assert len(d["per_rank"]["compressed_bytes"]) == world and all(c > 0 for c in d["per_rank"]["compressed_bytes"])
@@ -731,10 +764,12 @@ def test_rccl_preflight_at_world_size_one(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collectives", "--steps", "2", "--warmup", "1",
-           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-by-kind", "--init-timeout", "240"]
+           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-by-kind", "--init-timeout", "240",
+           "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    line, d = bench_line_and_detail(r, tmp_path)
+    assert line["collectives"]["backend"] == "nccl" and line["collectives"]["calls"] >= 6 and line["gather_probe"]["rccl"] is True
     c = d["collectives"]
     assert c["backend"] == "nccl" and c["through_torch_distributed"] is True and c["world"] == 1
     # the first barrier behind init, two around the timed steps, eight inside the gather probe's timing loop ...
@@ -773,10 +808,12 @@ def test_bench_line_carries_text_and_zipf_next_to_uniform(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--gib-per-gpu", "0.5", "--by-kind-steps", "2",
-           "--no-cpu-baseline", "--no-small-config"]
+           "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    line, d = bench_line_and_detail(r, tmp_path)
+    assert set(line["by_kind"]) == {"text", "zipf"} and all(k["ok"] is True and k["frac"] > 0 for k in line["by_kind"].values())
+    assert abs(line["by_kind"]["text"]["ratio"] - d["by_kind"]["text"]["compression_ratio"]) < 1e-5
     assert d["roofline"]["kernel"] in ("decode_slots_kernel", "encode_kernel") and d["roofline_encode"]["kernel"] == "encode_kernel"
     assert d["collectives"]["through_torch_distributed"] is False
     assert set(d["by_kind"]) == {"text", "zipf"}
@@ -791,7 +828,8 @@ def test_bench_line_carries_text_and_zipf_next_to_uniform(tmp_path):
 
 def test_bench_strong_scaling_splits_one_stream(tmp_path):
     """configs[3] in miniature: a fixed total split into contiguous packet ranges, one per rank."""
-    d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5", "--gib-per-gpu", "0.25"], tmp_path)
+    line, d = _self_launched_bench(["--scaling", "strong", "--total-gib", "0.5", "--gib-per-gpu", "0.25"], tmp_path)
+    assert line["scaling"] == "strong" and line["n_ranks_seen"] == 2
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong"
     assert d["roundtrip_equal"] is True and d["oracle_prefix_match"] is True
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 0.5 * 1.073741824) < 1e-6           # the total, not per rank

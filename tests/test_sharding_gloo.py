@@ -93,7 +93,18 @@ def _worker8(rank, world, port, q):
     rep = ctl.report()
     assert rep["backend"] == "gloo" and rep["world"] == world and rep["calls"] == {"barrier": 1, "all_reduce_max": 1, "all_reduce_min": 1, "all_gather": 1}
     assert fewest == 100
-    q.put((rank, rows, weak, slowest, hashlib.md5(seg.tobytes()).hexdigest(), args.scaling))
+    line = None
+    if rank == 0:
+        # the exact object and line rank 0 of `bench.py --gpus 8` makes of these rows: per-rank figures, the other scaling mode
+        # and the gather probe hung on it, cut to the stdout line by driver_line() and held to the driver's size rule
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import bench_stub
+        full = bench_stub.full_result(world, "strong", rows=rows)
+        full["collectives"] = rep
+        line = bench.driver_line(full, "bench_detail.json")
+        bench_stub.check_line(line, world)
+    q.put((rank, rows, weak, slowest, hashlib.md5(seg.tobytes()).hexdigest(), args.scaling, line))
     dist.destroy_process_group()
 
 
@@ -124,3 +135,14 @@ def test_eight_rank_control_plane_on_cpu():
     assert all(g[3] == 2.0 for g in got)                               # MAX over ranks
     whole = O.PortOracle().encode_stream(synth.generate("uniform", 42, total))
     assert sum(r[1] for r in rows0) == whole.size                      # the segment sizes add up to the whole stream's
+    # rank 0's stdout line, made of the rows the eight ranks really exchanged: it fits the driver's capture, is seen through
+    # the driver's tail behind the launcher's chatter, and carries eight ranks' worth of figures as min/max, not as arrays
+    import json
+    import bench_stub
+    line = got[0][6]
+    assert line is not None and all(g[6] is None for g in got[1:])
+    d = bench_stub.line_from_driver_tail("launcher chatter\n" * 500 + line + "\n", "warning\n" * 20)
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["scaling"] == "strong" and len(line) <= 4096
+    assert d["per_rank"] == {"encode_ms_min": 1.0, "encode_ms_max": 1.007, "decode_ms_min": 2.0, "decode_ms_max": 2.007}
+    assert d["collectives"] == {"backend": "gloo", "calls": 4}
+    assert abs(d["compression_ratio"] - (whole.size + 20) / total) < 1e-6
