@@ -778,6 +778,23 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // that kept a select of the increment there needed a lane mask carried between statements in a scalar register).
 // The same text serves the one wavefront of a file that holds its short last packet (lanes drop out under `if`).
 // It uses decode_wave's locals by name.
+// (timing experiments only, garbage out: profiles/r06_decode_step_budget.txt prices the step's LDS operations and waits by
+// building the kernel without them, one kind at a time)
+#ifdef GPUAR_EXP_NO_READS
+#define GPUAR_LDS_READ(TEXT) ""
+#else
+#define GPUAR_LDS_READ(TEXT) TEXT
+#endif
+#ifdef GPUAR_EXP_NO_ADDS
+#define GPUAR_LDS_ADD(TEXT) ""
+#else
+#define GPUAR_LDS_ADD(TEXT) TEXT
+#endif
+#ifdef GPUAR_EXP_NO_STREAM_READ
+#define GPUAR_LDS_STREAM_READ(TEXT) ""
+#else
+#define GPUAR_LDS_STREAM_READ(TEXT) TEXT
+#endif
 #define GPUAR_A_HEAD \
             "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 /* off = the low half of lo : off */ \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
@@ -791,13 +808,13 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_cndmask_b32 %[np], 0, 2, %[m0]\n\t" \
             "v_addc_co_u32 %[np], vcc, %[np], 0, %[m1]\n\t" /* complemented top two symbol bits */ \
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
-            "ds_read2_b64 v[200:203], %[am] offset1:64\n\t" /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
+            GPUAR_LDS_READ("ds_read2_b64 v[200:203], %[am] offset1:64\n\t") /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
 
 #define GPUAR_A_SHADOW_PLAIN \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
             64-bit LDS add (v204: +1 on the count, +0x10000 on the child if left; v205: the grandchild's, if left there); no field \
             can carry into its neighbour (counts stay below 2^14) */ \
-            "ds_add_u64 %[oaddr], v[204:205]\n\t"
+            GPUAR_LDS_ADD("ds_add_u64 %[oaddr], v[204:205]\n\t")
 // The same with the previous symbol's low half ADDRESSED here -- one shift-add off the end of the chain into a shadow in which
 // the wavefront waits anyway (round 4: 26.64 -> 26.42 ms).  Measured and not kept: the filing of the previous symbol here
 // as well (its last decision's lane mask saved by s_mov_b64 and put back into vcc in front of the SDWA add-with-carry:
@@ -807,8 +824,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // chain): +3 cycles, this shadow has no room left.
 #define GPUAR_A_SHADOW_DEFERRED \
             "v_lshl_add_u32 %[oaddr], %[c6], 9, %[collow]\n\t" \
-            "ds_add_u64 %[oaddr], v[204:205]\n\t"
-#define GPUAR_A_TAIL \
+            GPUAR_LDS_ADD("ds_add_u64 %[oaddr], v[204:205]\n\t")
+#define GPUAR_REG_NODES \
          /* register nodes += went left: the root by the first decision's mask, of the two depth-1 nodes the one on the path by \
             the second one's -- which of them it is, is settled between the two lane masks by the scalar unit (both were written \
             a dozen instructions ago: no wait), so each node takes ONE add-with-carry (rounds 2-4: the chosen node's copy bumped, \
@@ -817,21 +834,50 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "s_andn2_b64 %[mj], %[m1], %[m0]\n\t" \
             "v_addc_co_u32 %[root], vcc, %[root], 0, %[m0]\n\t" \
             "v_addc_co_u32 %[h0], vcc, %[h0], 0, %[sx]\n\t" \
-            "v_addc_co_u32 %[h1], vcc, %[h1], 0, %[mj]\n\t" \
-            GPUAR_STREAM_EARLY
+            "v_addc_co_u32 %[h1], vcc, %[h1], 0, %[mj]\n\t"
+// Where a step bumps its register nodes: in its first LDS shadow (rounds 2-5) or in its second (vcc and mj are free there too).
+// The even step keeps them in the first shadow; the odd step -- whose first shadow holds the stream reader's move and read and
+// whose second would otherwise wait -- bumps them in the second (round 6 A/B on uniform 8 GiB: 25.13 -> 24.76 ms; both steps in
+// the second shadow 25.20, only the even step 25.59).  After this both waits of a step are worth 3-6 cycles: the step's time is
+// its instructions' issue time (profiles/r06_decode_step_budget.txt).
+#ifndef GPUAR_DEC_NODES_PLACE
+#define GPUAR_DEC_NODES_PLACE 1
+#endif
+#define GPUAR_NODES_NOWHERE ""
+#if GPUAR_DEC_NODES_PLACE == 0
+#define GPUAR_NODES_EVEN_EARLY GPUAR_REG_NODES
+#define GPUAR_NODES_EVEN_LATE ""
+#define GPUAR_NODES_ODD_EARLY GPUAR_REG_NODES
+#define GPUAR_NODES_ODD_LATE ""
+#elif GPUAR_DEC_NODES_PLACE == 1
+#define GPUAR_NODES_EVEN_EARLY GPUAR_REG_NODES
+#define GPUAR_NODES_EVEN_LATE ""
+#define GPUAR_NODES_ODD_EARLY ""
+#define GPUAR_NODES_ODD_LATE GPUAR_REG_NODES
+#elif GPUAR_DEC_NODES_PLACE == 2
+#define GPUAR_NODES_EVEN_EARLY ""
+#define GPUAR_NODES_EVEN_LATE GPUAR_REG_NODES
+#define GPUAR_NODES_ODD_EARLY ""
+#define GPUAR_NODES_ODD_LATE GPUAR_REG_NODES
+#elif GPUAR_DEC_NODES_PLACE == 3
+#define GPUAR_NODES_EVEN_EARLY ""
+#define GPUAR_NODES_EVEN_LATE GPUAR_REG_NODES
+#define GPUAR_NODES_ODD_EARLY GPUAR_REG_NODES
+#define GPUAR_NODES_ODD_LATE ""
+#endif
 
 // (the path after the record's first decision stays in `np` -- the two later ones go on in t3 -- so that the address of the
 // half that takes the increments is formed behind read #2, next to the LDS add that uses it, and not on the chain)
 #define GPUAR_MID_WRITEBACK \
             "v_addc_co_u32 %[t3], %[mj], %[t3], %[t3], %[mc]\n\t" \
             "v_lshl_add_u32 %[oaddr], %[t3], 10, %[collow]\n\t" \
-            "ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t" /* READ #2: low record */ \
+            GPUAR_LDS_READ("ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t") /* READ #2: low record */ \
          /* ---- the mid half takes its increments by one 64-bit LDS add in the shadow of read #2 */ \
             "v_lshl_add_u32 %[am], %[np], 9, %[col]\n\t" /* where that half lives: its index is the path up to the record's first decision */ \
             "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
             "v_cndmask_b32 %[t2], 1, %[k64k], vcc\n\t" \
             "v_cndmask_b32 v209, 0, %[t2], %[mc]\n\t" \
-            "ds_add_u64 %[am], v[208:209]\n\t"
+            GPUAR_LDS_ADD("ds_add_u64 %[am], v[208:209]\n\t")
 #ifdef GPUAR_EXP_NO_WAIT1      /* (timing experiments only: garbage out) */
 #define GPUAR_WAIT1 ""
 #else
@@ -842,8 +888,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #else
 #define GPUAR_WAIT2 "s_waitcnt lgkmcnt(1)\n\t"
 #endif
-#define GPUAR_BC_MID \
-            GPUAR_WAIT1 /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
+#define GPUAR_BC_MID(WAIT1) \
+            WAIT1 /* read #1 is back (LDS completes in order: at most the write behind it is left) */ \
          /* ---- mid record: v200 = aR | bR << 16, v201 = cRR | cRL << 16 (right half), v202 = a | bL << 16, v203 = cLR | cLL << 16 (left half) */ \
             "v_mul_u32_u24_sdwa %[t0], v202, %[rng]" GPUAR_SDWA_W0 \
             "v_sub_co_u32 %[t1], %[ma], %[R], %[t0]\n\t" \
@@ -926,31 +972,96 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #define GPUAR_FILE_SYMBOL(J) \
             "v_addc_co_u32_sdwa %[word], vcc, %[c7], %[c7], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
-// The stream reader between the two halves, in the shadow of read #1: the window (w0:w1, `rem` unread bits of
-// w0) steps over the previous symbol's n bits; a lane whose w0 ran out moves w1 up, takes the dword it asked
-// for at its previous refill and asks for the next one -- from its 64-byte ring in LDS (dword-major, lane-minor:
-// dword d of lane l at ring region + 256 * d + 4 * l, so the 64 lanes of a read hit 64 different banks whatever
-// dwords they are at; `next` is the reader's byte offset times 64, i.e. already 256 * dword index; decode_wave
-// keeps the ring filled).  The ds_read of
-// `ahead` is never waited for by itself: it is older than the record read of this very symbol, whose
-// s_waitcnt lgkmcnt(1) (LDS operations complete in order) comes long before the next refill reads `ahead`.
-// The window's borrow is formed EARLY (GPUAR_STREAM_EARLY: the tail of the first shadow, into a scalar pair of its own) and
-// only read here: a lane mask that a vector instruction has just written is not there yet for the scalar unit, and
-// s_and_saveexec right behind its v_sub_co (rounds 2-3) stalled the wavefront for 12 cycles per symbol.
-#define GPUAR_STREAM_EARLY \
-            "v_sub_co_u32 %[rem], %[sb], %[rem], %[n]\n\t" /* borrow: w0 ran out */ \
-            "v_and_b32 %[rem], 31, %[rem]\n\t"
-#define GPUAR_STREAM_HEAD \
-            "s_and_saveexec_b64 %[sx], %[sb]\n\t" /* (no branch around the region: some lane refills on almost every symbol) */
-#define GPUAR_STREAM_TEXT \
-            GPUAR_STREAM_HEAD \
-            "v_mov_b32 %[w0], %[w1]\n\t" \
-            "v_perm_b32 %[w1], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
-            "v_and_or_b32 %[t0], %[next], %[kf00], %[ring]\n\t" /* ring + 256 * (dword index mod 16) */ \
-            "ds_read_b32 %[ahead], %[t0]\n\t" \
-            "v_add_u32 %[next], 0x100, %[next]\n\t" \
-            "s_or_b64 exec, exec, %[sx]\n\t" \
+// The stream reader.  What a step needs of the stream is the window v216: the next stream bits, left-aligned, of which the
+// 64-bit shift at the end of the step (GPUAR_OFF_TEXT) moves the top n <= 16 into lo : off -- and leaves v216 = window << n,
+// i.e. ALREADY stepped over the bits it took.  So v216 filled with 32 fresh bits lasts TWO symbols whatever they consume, and
+// the reader runs at a fixed cadence, in all lanes alike, with no lane mask on exec.  (Rounds 1-5 refilled under a saved exec
+// mask on every symbol -- 7 vector + 1 LDS + 2 scalar instructions per symbol, some lane needing it almost every time; now
+// 10 + 1 + 0 per TWO symbols.)
+//   EVEN step (symbols 0, 2, 4, ... of a block): the bits of the two symbols before it come off `rem` (unread bits of w0) in
+//     one subtraction; its borrow says that w0 ran out: w1 moves up and takes the dword `ahead` (swapped to big-endian order
+//     here); v216 = the 32 bits at `rem`.
+//   ODD step: the lanes whose w0 ran out move their reader on by a dword, and every lane -- moved or not -- reads `ahead` again
+//     from where its reader now stands (the lane's 64-byte ring in LDS, dword-major / lane-minor: dword d of lane l at ring
+//     region + 256 * d + 4 * l, so the 64 lanes of a read hit 64 different banks whatever dwords they are at; `next` is the
+//     byte offset of that dword times 64, i.e. already 256 * dword index; decode_wave keeps the ring filled).
+// The even step's selects read the borrow as a lane mask (a scalar pair that only vector instructions read: nothing goes
+// through the scalar unit); the odd step takes the same fact from the sign of the unwrapped difference, a vector register.  The read of `ahead` is never waited for by itself: it
+// is older than the record reads of the next step, whose s_waitcnt lgkmcnt(1) (LDS operations complete in order) comes before
+// the next even step looks at `ahead`.
+// Where the pieces sit was settled by timing (profiles/r06_decode_step_budget.txt, uniform 8 GiB, one box, rounds 4-5's per-symbol
+// reader 26.4-26.5 ms): the whole reader in the even step's second LDS shadow 25.8; split between the two steps' second shadows
+// 25.8; the even step's subtraction moved to its first shadow 25.6; the odd step's part in ITS first shadow as well 25.2-25.3
+// (kept); everything in first shadows 25.7.  A shadow hides three or four instructions, not ten.
+#define GPUAR_STREAM_PART_A \
+            "v_add_u32 %[pc], %[nprev], %[n]\n\t" /* the bits of the two symbols since the last refill: <= 32 */ \
+            "v_sub_co_u32 %[raw], %[sb], %[rem], %[pc]\n\t" /* borrow: w0 ran out */ \
+            "v_and_b32 %[rem], 31, %[raw]\n\t"
+#define GPUAR_STREAM_PART_B \
+            "v_perm_b32 %[pa], 0, %[ahead], %[bsw]\n\t" /* big-endian order restored */ \
+            "v_cndmask_b32 %[w0], %[w0], %[w1], %[sb]\n\t" \
+            "v_cndmask_b32 %[w1], %[w1], %[pa], %[sb]\n\t" \
             "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t" /* the next 32 stream bits */
+#define GPUAR_STREAM_PART_C \
+            "v_lshrrev_b32 %[pb], 31, %[raw]\n\t" /* the difference before it was wrapped: negative where w0 ran out */ \
+            "v_lshl_add_u32 %[next], %[pb], 8, %[next]\n\t" \
+            "v_and_or_b32 %[pc], %[next], %[kf00], %[ring]\n\t" /* ring + 256 * (dword index mod 16) */ \
+            GPUAR_LDS_STREAM_READ("ds_read_b32 %[ahead], %[pc]\n\t")
+#ifndef GPUAR_DEC_STREAM_PLACE
+#define GPUAR_DEC_STREAM_PLACE 6
+#endif
+#define GPUAR_STREAM_ODD_EARLY ""
+#define GPUAR_STREAM_ODD_TEXT ""
+#define GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY GPUAR_WAIT1
+#define GPUAR_WAIT1_GPUAR_STREAM_EVEN_EARLY GPUAR_WAIT1
+#ifdef GPUAR_EXP_NO_STREAM               /* (timing experiments only, garbage out: no stream instruction in any step) */
+#define GPUAR_STREAM_EVEN_EARLY ""
+#define GPUAR_STREAM_EVEN_TEXT ""
+#elif GPUAR_DEC_STREAM_PLACE == 2        /* (A/B) all of it in the even step's second shadow */
+#define GPUAR_STREAM_EVEN_EARLY ""
+#define GPUAR_STREAM_EVEN_TEXT GPUAR_STREAM_PART_A GPUAR_STREAM_PART_B GPUAR_STREAM_PART_C
+#elif GPUAR_DEC_STREAM_PLACE == 4        /* (A/B) the reader's move and the read of `ahead` one step later, in the ODD step's second shadow */
+#define GPUAR_STREAM_EVEN_EARLY ""
+#define GPUAR_STREAM_EVEN_TEXT GPUAR_STREAM_PART_A GPUAR_STREAM_PART_B
+#undef GPUAR_STREAM_ODD_TEXT
+#define GPUAR_STREAM_ODD_TEXT GPUAR_STREAM_PART_C
+#elif GPUAR_DEC_STREAM_PLACE == 5        /* (A/B) as 4, with the subtraction in the even step's first shadow */
+#define GPUAR_STREAM_EVEN_EARLY GPUAR_STREAM_PART_A
+#define GPUAR_STREAM_EVEN_TEXT GPUAR_STREAM_PART_B
+#undef GPUAR_STREAM_ODD_TEXT
+#define GPUAR_STREAM_ODD_TEXT GPUAR_STREAM_PART_C
+#elif GPUAR_DEC_STREAM_PLACE == 6        /* the subtraction in the even step's first shadow, the selects and the window in its second; the odd step's part in ITS first shadow (two LDS operations behind read #1) */
+#define GPUAR_STREAM_EVEN_EARLY GPUAR_STREAM_PART_A
+#define GPUAR_STREAM_EVEN_TEXT GPUAR_STREAM_PART_B
+#undef GPUAR_STREAM_ODD_EARLY
+#define GPUAR_STREAM_ODD_EARLY GPUAR_STREAM_PART_C
+#undef GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY
+#define GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY "s_waitcnt lgkmcnt(2)\n\t"
+#elif GPUAR_DEC_STREAM_PLACE == 10       /* (A/B) as 6, the byte swap in the even step's first shadow as well */
+#define GPUAR_STREAM_EVEN_EARLY GPUAR_STREAM_PART_A "v_perm_b32 %[pa], 0, %[ahead], %[bsw]\n\t"
+#define GPUAR_STREAM_EVEN_TEXT \
+            "v_cndmask_b32 %[w0], %[w0], %[w1], %[sb]\n\t" \
+            "v_cndmask_b32 %[w1], %[w1], %[pa], %[sb]\n\t" \
+            "v_alignbit_b32 v216, %[w0], %[w1], %[rem]\n\t"
+#undef GPUAR_STREAM_ODD_EARLY
+#define GPUAR_STREAM_ODD_EARLY GPUAR_STREAM_PART_C
+#undef GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY
+#define GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY "s_waitcnt lgkmcnt(2)\n\t"
+#elif GPUAR_DEC_STREAM_PLACE == 7        /* (A/B) everything in first shadows */
+#define GPUAR_STREAM_EVEN_EARLY GPUAR_STREAM_PART_A GPUAR_STREAM_PART_B
+#define GPUAR_STREAM_EVEN_TEXT ""
+#undef GPUAR_STREAM_ODD_EARLY
+#define GPUAR_STREAM_ODD_EARLY GPUAR_STREAM_PART_C
+#undef GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY
+#define GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY "s_waitcnt lgkmcnt(2)\n\t"
+#elif GPUAR_DEC_STREAM_PLACE == 9        /* (A/B) the even step's part in its second shadow, the odd step's in its first */
+#define GPUAR_STREAM_EVEN_EARLY ""
+#define GPUAR_STREAM_EVEN_TEXT GPUAR_STREAM_PART_A GPUAR_STREAM_PART_B
+#undef GPUAR_STREAM_ODD_EARLY
+#define GPUAR_STREAM_ODD_EARLY GPUAR_STREAM_PART_C
+#undef GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY
+#define GPUAR_WAIT1_GPUAR_STREAM_ODD_EARLY "s_waitcnt lgkmcnt(2)\n\t"
+#endif
 
 // lo' : off' = (((lo + dn) : (off - dn)) : window) << n, upper half, with lo's top bit cleared: ONE 64-bit shift moves both
 // (v217 = lo << 16 | off, the window in v216).  What leaves lo at the top falls off the register; (off - dn + 1) << n
@@ -962,10 +1073,10 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 
 #define GPUAR_STEP_OPERANDS_COMMON \
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
-              [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), [sb] "=&s"(sb), \
+              [m0] "=&s"(m0), [m1] "=&s"(m1), [ma] "=&s"(ma), [mc] "=&s"(mc), [mj] "=&s"(mj), [sx] "=&s"(sx), [sb] "=&s"(sb), [raw] "+v"(rem_raw), \
               [root] "+v"(dec.model.root), [h0] "+v"(dec.model.half0), [h1] "+v"(dec.model.half1), \
               [rng] "+v"(dec.range), [off] "+v"(offr), [kff] "+v"(kff), [oaddr] "+v"(oaddr), \
-              [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), [n] "+v"(nbits), \
+              [rem] "+v"(dec.rem), [w0] "+v"(dec.w0), [w1] "+v"(dec.w1), [ahead] "+v"(dec.ahead), [next] "+v"(next64), "+v"(window), \
               [dn] "=&v"(dn), [bw] "=&v"(bw), [cc] "=&v"(cc), [pa] "=&v"(pa), [pb] "=&v"(pb), [pc] "=&v"(pc), [ps] "=&v"(ps), \
               [wd] "=&v"(wd), [h] "=&v"(h), [e] "=&v"(e)
 
@@ -973,8 +1084,10 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx, sb;
 
-// TEXT: the step's instruction text (one of the three below); WORD: the output word the symbol is filed in
-#define GPUAR_DECODE_STATEMENT(TEXT, K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD) \
+// TEXT: the step's instruction text (one of the kinds below); WORD: the output word the symbol is filed in; N: where this
+// step leaves the number of stream bits it took (even and odd steps have a register each: the even step's refill needs both)
+// and N_PREV the other one
+#define GPUAR_DECODE_STATEMENT(TEXT, K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD, N, N_PREV) \
     { \
         GPUAR_STEP_LOCALS \
         uint32_t lbw_, lcc_, ti_, path7_; \
@@ -982,26 +1095,27 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         asm volatile(TEXT \
             : GPUAR_STEP_OPERANDS_COMMON, \
               [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1), \
-              [c6] "+v"(path6), [c7] "=&v"(path7_) \
-            : [tot] "s"((K_TOTAL)), [mul] "v"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
+              [c6] "+v"(path6), [c7] "=&v"(path7_), [n] "+v"(N) \
+            : [nprev] "v"(N_PREV), [tot] "s"((K_TOTAL)), [mul] "v"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
               [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [tbase] "s"((K_TOTAL0_M1)), [tj] "n"(POS) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215", "v216"); \
+            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215"); \
     }
-// The three kinds of step in a loop body of 32 symbols: all but the last leave the address of their low half to the next
+// The kinds of step in a loop body of 32 symbols.  By position: all but the last leave the address of their low half to the next
 // step's first LDS shadow (the path after six decisions stays in a register of its own, `path6`), all but the first form it
-// there for their predecessor.
+// there for their predecessor.  By parity: even steps refill the stream window, odd steps live on what the even one left.
+#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J) \
+    GPUAR_A_HEAD SHADOW GPUAR_NODES_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_EARLY GPUAR_BC_MID(GPUAR_WAIT1_GPUAR_STREAM_##PARITY##_EARLY) \
+    GPUAR_STREAM_##PARITY##_TEXT GPUAR_NODES_##PARITY##_LATE GPUAR_BC_LOW(OWN_ADDRESS) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
 #ifdef GPUAR_DEC_NO_DEFER      /* (A/B builds: every step forms its own address, as in rounds 2-4a) */
-#define GPUAR_STEP_FIRST(J) \
-    GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW(GPUAR_LOW_ADDRESS_NOW) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
-#define GPUAR_STEP_MIDDLE(J) GPUAR_STEP_FIRST(J)
-#define GPUAR_STEP_LAST(J) GPUAR_STEP_FIRST(J)
+#define GPUAR_STEP_FIRST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, GPUAR_LOW_ADDRESS_NOW, J)
+#define GPUAR_STEP_EVEN(J) GPUAR_STEP_FIRST(J)
+#define GPUAR_STEP_ODD(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, ODD, GPUAR_LOW_ADDRESS_NOW, J)
+#define GPUAR_STEP_LAST(J) GPUAR_STEP_ODD(J)
 #else
-#define GPUAR_STEP_FIRST(J) \
-    GPUAR_A_HEAD GPUAR_A_SHADOW_PLAIN GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW() GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
-#define GPUAR_STEP_MIDDLE(J) \
-    GPUAR_A_HEAD GPUAR_A_SHADOW_DEFERRED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW() GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
-#define GPUAR_STEP_LAST(J) \
-    GPUAR_A_HEAD GPUAR_A_SHADOW_DEFERRED GPUAR_A_TAIL GPUAR_BC_MID GPUAR_STREAM_TEXT GPUAR_BC_LOW(GPUAR_LOW_ADDRESS_NOW) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#define GPUAR_STEP_FIRST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, , J)
+#define GPUAR_STEP_EVEN(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, EVEN, , J)
+#define GPUAR_STEP_ODD(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, , J)
+#define GPUAR_STEP_LAST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, GPUAR_LOW_ADDRESS_NOW, J)
 #endif
 
 // LDS of a decoder workgroup (one wavefront): the 64 models and the 64 stream rings, 40 KiB -> four per CU.
@@ -1039,7 +1153,13 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     register uint32_t o1 asm("v205");
     register uint32_t offr asm("v217");        // lo << 16 | (code - lo): v216:v217 is the pair the 64-bit shift works on, and
     offr = dec.off | (dec.lo << 16);           // lower bound and code offset move through the step as ONE register
-    uint32_t nbits = dec.owed_bits;            // bits of the previous symbol the stream window still has to step over
+    // the stream bits the last two symbols took and the reader has not stepped over yet: the even step's and the odd step's, a
+    // register each (GPUAR_STREAM_EVEN_EARLY takes both off `rem` at once)
+    uint32_t n_even = 0, n_odd = dec.owed_bits;
+    uint32_t rem_raw = 0;                      // the even step's `rem` before it was wrapped into 0..31: negative where w0 ran out -- the odd step
+                                               // behind it moves those lanes' reader on (a vector register: nothing crosses statements as a lane mask)
+    register uint32_t window asm("v216");      // the stream bits in front of the reader, left-aligned: filled by every even step, shifted
+    asm volatile("v_mov_b32 %0, 0" : "=v"(window));       // on by every step (the low half of the pair the 64-bit shift works on)
     const uint32_t col_low_lds = col_lds + SubtreeModel<9>::kLowBase;               // ... and of its first low half
     uint32_t oaddr = col_lds + dec.model.owed.at;                                   // where the half owed goes
     // (No check for "a code value no symbol owns" -- off >= range, where the reference stops decoding, :873-877 -- in
@@ -1067,15 +1187,22 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // may be read the last such piece is repeated (a well-formed packet decodes the same whatever follows).
     // A lane consumes at most 16 bits per symbol (n = e + u <= 16: range' = width << n <= 2^16, whatever the
     // bits are) = 16 bytes per phase of EIGHT symbols (rounds 1-3 reckoned with 31 bits and ran the phase every
-    // four), a phase brings 16: asking for piece P once the reader is within 48 bytes of it keeps >= 17 bytes in
-    // LDS ahead of the reader (the gap at a phase never falls below 33 bytes), and the piece P overwrites
-    // (P - 64) has been read completely by then.
+    // four), a phase brings 16.  The reader's position A is the offset of the dword `ahead` holds, as of the last even step
+    // (which has taken off the bits of all symbols before it): that dword is read AGAIN at every even step until the reader
+    // moves on, so everything from A on must stay in the ring.  Asking for piece P = `fill` once fill - A <= 48: (1) the piece
+    // P overwrites, P - 64, ends at or below A when P is written a phase later (A only grows); (2) the gap fill - A at a phase
+    // never falls below 33 (49 or more and nothing is asked for: the next phase sees 16 less at most; below that a piece is asked
+    // for and the gap keeps its size), while the even steps up to the next phase read dwords below A + 16 + 4 <= fill, all
+    // written by then.  The ring starts full from the piece that holds `ahead` (gap >= 49).
     const uint32_t skew16 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) & 15u);
     const uint8_t *base16 = base - skew16;
     const uint32_t next16 = dec.next + skew16;                   // offset from base16 of the dword after `ahead` ...
-    uint32_t next64 = next16 << 6;                               // ... carried times 64: bits 8-11 = 256 * (dword index mod 16)
+    // ... and, times 64 (bits 8-11 = 256 * (dword index mod 16)), of the dword `ahead` holds itself: the even step reads
+    // `ahead` again from where the reader stands whether or not it has moved
+    uint32_t next64 = (next16 - 4u) << 6;
     const uint32_t last_piece = (dec.last + skew16) & ~15u;
-    uint32_t fill = (next16 & ~15u) + 16u * kRingPieces;         // offset of the next piece to ask for
+    const uint32_t first_piece = (next16 - 4u) & ~15u;           // the piece that holds `ahead`'s dword: the ring starts there
+    uint32_t fill = first_piece + 16u * kRingPieces;             // offset of the next piece to ask for
     // piece `at` (a multiple of 16) = dwords 4p .. 4p+3 of the ring, p = (at / 16) mod 4: two ds_write2st64_b32
     register uint32_t q0 asm("v220");          // the piece asked for last (in flight, or already in the ring:
     register uint32_t q1 asm("v221");          // writing it a second time is harmless) ...
@@ -1084,7 +1211,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     uint32_t slot_lds = ring_lds;              // ... and the LDS address of its dword 0
 #pragma unroll
     for (uint32_t k = 0; k < kRingPieces; ++k) {
-        const uint32_t at = (next16 & ~15u) + 16u * k;
+        const uint32_t at = first_piece + 16u * k;
         const Quad q = load128(base16 + (at < last_piece ? at : last_piece));
         uint32_t *slot = reinterpret_cast<uint32_t *>(ring + ((at & 0x30u) << 6));
         slot[0] = q.w[0], slot[64] = q.w[1], slot[128] = q.w[2], slot[192] = q.w[3];
@@ -1103,7 +1230,12 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 // knows them as the pinned variables m<SET>0..7) -- where the step's two v_mul_hi_u32 take it from directly.  The
 // loads land before the next phase's s_waitcnt vmcnt(0), one whole run before they are used.  (Rounds 2-3 kept symbol j's
 // multiplier in lane j of ONE register per block of 64 and fetched it with a v_readlane per symbol.)
-#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI)                                                        \
+#ifdef GPUAR_EXP_NO_RING        /* (timing experiments only, garbage out: no ring phase at all) */
+#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI)
+#else
+#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI) GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)
+#endif
+#define GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)                                                   \
     {                                                                                                                \
         uint32_t t_, t2_;                                                                                            \
         unsigned long long sx_;                                                                                      \
@@ -1156,14 +1288,14 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             const uint32_t total0 = 256u + i + j0;                                                                   \
             const uint32_t total0_m1 = 255u + i + j0; /* each step adds its position in the run as an inline constant */ \
             /* every symbol goes into its own byte of its word */                                                    \
-            GPUAR_DECODE_STATEMENT(FIRST_KIND(0), total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A)              \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(1), total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A)  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(2), total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A)  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(3), total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A)  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(0), total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B)  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(1), total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B)  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_MIDDLE(2), total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B)  \
-            GPUAR_DECODE_STATEMENT(LAST_KIND(3), total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B)          \
+            GPUAR_DECODE_STATEMENT(FIRST_KIND(0), total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A, n_even, n_odd)                  \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(1), total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A, n_odd, n_even)        \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(2), total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A, n_even, n_odd)       \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(3), total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A, n_odd, n_even)        \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(0), total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B, n_even, n_odd)       \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(1), total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B, n_odd, n_even)        \
+            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(2), total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B, n_even, n_odd)       \
+            GPUAR_DECODE_STATEMENT(LAST_KIND(3), total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B, n_odd, n_even)             \
             /* ... and fetches the multipliers of the run after next: 8 * (RUN + 2) dwords behind the half block's first */ \
             GPUAR_RING_PHASE(32 * ((RUN) + 2), SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
         }
@@ -1171,6 +1303,11 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 // of its own by name -- rounds 1-3 looped over runs of eight and filed each word into a register array by index (a
 // v_not, an s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off and a scalar add per word, 1.5 issue slots per symbol, plus
 // the loop's own six per eight symbols).
+#ifdef GPUAR_EXP_NO_STORES      /* (timing experiments only: the decoded bytes never leave; a condition the compiler cannot fold) */
+#define GPUAR_EXP_STORES (len_max > 0x7FFFFFF0u)
+#else
+#define GPUAR_EXP_STORES true
+#endif
 #define GPUAR_DECODE_BLOCK                                                                                           \
     {                                                                                                                \
         /* the shift that goes with the multipliers: floor(log2(total)) - 1, the same for all 64 totals of a block */ \
@@ -1181,16 +1318,16 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             /* the body, read by all but the first; defined here, for the compiler, without an instruction)                */ \
             uint32_t path6;                                                                                          \
             asm volatile("" : "=v"(path6));                                                                          \
-            GPUAR_DECODE_RUN8(0, GPUAR_STEP_FIRST, GPUAR_STEP_MIDDLE, w0, w1, 2, "v[240:243]", "v[244:247]")         \
-            GPUAR_DECODE_RUN8(1, GPUAR_STEP_MIDDLE, GPUAR_STEP_MIDDLE, w2, w3, 3, "v[248:251]", "v[252:255]")        \
-            GPUAR_DECODE_RUN8(2, GPUAR_STEP_MIDDLE, GPUAR_STEP_MIDDLE, w4, w5, 0, "v[224:227]", "v[228:231]")        \
-            GPUAR_DECODE_RUN8(3, GPUAR_STEP_MIDDLE, GPUAR_STEP_LAST, w6, w7, 1, "v[232:235]", "v[236:239]")          \
+            GPUAR_DECODE_RUN8(0, GPUAR_STEP_FIRST, GPUAR_STEP_ODD, w0, w1, 2, "v[240:243]", "v[244:247]")            \
+            GPUAR_DECODE_RUN8(1, GPUAR_STEP_EVEN, GPUAR_STEP_ODD, w2, w3, 3, "v[248:251]", "v[252:255]")             \
+            GPUAR_DECODE_RUN8(2, GPUAR_STEP_EVEN, GPUAR_STEP_ODD, w4, w5, 0, "v[224:227]", "v[228:231]")             \
+            GPUAR_DECODE_RUN8(3, GPUAR_STEP_EVEN, GPUAR_STEP_LAST, w6, w7, 1, "v[232:235]", "v[236:239]")            \
             /* the block's 64 bytes leave TOGETHER, as four back-to-back 16-byte stores (a whole 64-byte sector: with two */ \
             /* stores per half block the L2 wrote 5 % and fetched 9 % more than the bytes): the first half's words wait,    */ \
             /* complemented, in k0..k7 (the path bits are the COMPLEMENTED symbol bits)                                     */ \
             if (half == 0u) {                                                                                        \
                 k0 = ~w0, k1 = ~w1, k2 = ~w2, k3 = ~w3, k4 = ~w4, k5 = ~w5, k6 = ~w6, k7 = ~w7;                      \
-            } else {                                                                                                 \
+            } else if (GPUAR_EXP_STORES) {                                                                           \
                 uint4 *dst = reinterpret_cast<uint4 *>(out + i);                                                     \
                 dst[0] = make_uint4(k0, k1, k2, k3);                                                                 \
                 dst[1] = make_uint4(k4, k5, k6, k7);                                                                 \
@@ -1232,13 +1369,14 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 #undef GPUAR_DECODE_BLOCK
 #undef GPUAR_DECODE_RUN8
 #undef GPUAR_RING_PHASE
+#undef GPUAR_RING_PHASE_TEXT
     // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
     // (and a piece the last ring phase asked for may still be on its way into v220-v223)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(dec.ahead), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
-    dec.next = (next64 >> 6) - skew16;
+    dec.next = (next64 >> 6) + 4u - skew16;    // (next64 is the offset of `ahead`'s own dword, dec.next of the one behind it)
     dec.off = offr & 0xFFFFu;
     dec.lo = (offr >> 16) & 0x7FFFu;           // (the step leaves lo's top bit to the next step's shadow)
-    dec.owed_bits = nbits;
+    dec.owed_bits = n_even + n_odd;            // what the last two symbols took is still to be stepped over (skip() takes up to 32 bits at once)
     // the increment still owed goes in now; what the plain step is then handed as "owed" is a rewrite of that half with
     // the values it holds (its write_back stores, it does not add)
     asm volatile("ds_add_u64 %[oaddr], v[204:205]\n\ts_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1) : [oaddr] "v"(oaddr) : "memory");
