@@ -911,7 +911,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // or left to the next step's first shadow (empty; GPUAR_A_SHADOW_DEFERRED)
 #define GPUAR_LOW_ADDRESS_NOW \
             "v_lshl_add_u32 %[oaddr], %[c6], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */
-#define GPUAR_BC_LOW(OWN_ADDRESS) \
+#define GPUAR_BC_LOW(OWN_ADDRESS) GPUAR_BC_LOW_WALK_TEXT(OWN_ADDRESS) GPUAR_BC_LOW_INTERVAL
+#define GPUAR_BC_LOW_WALK_TEXT(OWN_ADDRESS) \
             GPUAR_WAIT2 /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
          /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
                  Next to the walk (three decisions on the scaled remainder) the symbol's own COUNT is picked out of the half: \
@@ -941,7 +942,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_sub_co_u32 %[t1], vcc, %[R], %[pc]\n\t" \
             "v_sub_u32 %[t3], %[ps], %[t2]\n\t" /* the right leaf */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
-            "v_cndmask_b32 %[t3], %[t3], %[t2], vcc\n\t" /* cnt(symbol) */ \
+            "v_cndmask_b32 %[t3], %[t3], %[t2], vcc\n\t" /* cnt(symbol) */
+#define GPUAR_BC_LOW_INTERVAL \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_mad_u32_u24 %[t1], %[t3], %[rng], %[t0]\n\t" /* cumHi * range = cumLo * range + cnt * range */ \
@@ -1103,9 +1105,21 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // The kinds of step in a loop body of 32 symbols.  By position: all but the last leave the address of their low half to the next
 // step's first LDS shadow (the path after six decisions stays in a register of its own, `path6`), all but the first form it
 // there for their predecessor.  By parity: even steps refill the stream window, odd steps live on what the even one left.
+#ifdef GPUAR_EXP_NO_SEARCH      /* (timing experiments only, garbage out: the step WITHOUT its symbol search -- no decision, no record read, no
+                                   increment, no register-node update: what every decoder of this format pays per symbol whatever finds the symbol,
+                                   profiles/r06_latency_decoder_prototype.txt) */
+#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J) \
+            "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 \
+            "v_add3_u32 %[R0], %[R0], %[tbase], %[tj]\n\t" \
+            "v_lshrrev_b32 %[R], 1, %[R0]\n\t" \
+            "v_mov_b32 %[t3], 1\n\t" \
+            "v_mov_b32 %[c7], %[c6]\n\t" \
+            GPUAR_STREAM_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_TEXT GPUAR_BC_LOW_INTERVAL GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#else
 #define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J) \
     GPUAR_A_HEAD SHADOW GPUAR_NODES_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_EARLY GPUAR_BC_MID(GPUAR_WAIT1_GPUAR_STREAM_##PARITY##_EARLY) \
     GPUAR_STREAM_##PARITY##_TEXT GPUAR_NODES_##PARITY##_LATE GPUAR_BC_LOW(OWN_ADDRESS) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#endif
 #ifdef GPUAR_DEC_NO_DEFER      /* (A/B builds: every step forms its own address, as in rounds 2-4a) */
 #define GPUAR_STEP_FIRST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, GPUAR_LOW_ADDRESS_NOW, J)
 #define GPUAR_STEP_EVEN(J) GPUAR_STEP_FIRST(J)
