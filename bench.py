@@ -74,6 +74,9 @@ def parse_args(argv=None):
                     help="seconds init_process_group and the first barrier may take before the run gives up with one clear line")
     ap.add_argument("--force-collectives", action="store_true",
                     help="route barrier / MAX / all_gather through torch.distributed (RCCL) even at world size 1: the RCCL preflight")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not start the two rocprofv3 --pmc child runs that measure the coder kernels' HBM bytes on this box")
+    ap.add_argument("--live-traffic-timeout", type=float, default=150.0, help="seconds each of the two counter passes may take")
     ap.add_argument("--detail-file", default=None,
                     help=f"where the full result object goes (default: {DETAIL_FILE} next to bench.py, and a copy under gpurun_out/ when that exists)")
     return ap.parse_args(argv)
@@ -245,6 +248,70 @@ def load_profiled_traffic(kind, n_bytes, root=ROOT, stamp=None):
     return {"source": "; ".join(why[:3])}
 
 
+def live_traffic(kind, seed, n_bytes, timeout_s, root=ROOT):
+    """HBM bytes per launch of the two coder kernels, MEASURED ON THIS BOX in this run: two fresh child processes,
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/prof_run.py ...` and the same with WRITE_SIZE (the two counters do
+    not fit one pass, /opt/skills/guides/MI355X_MICROARCH.md), on the same stream kind and size as the timed pass, after it and
+    with its buffers freed.  The program itself follows `--` (no shell, no env, no exec of this GPU-holding process); each pass
+    has its own timer and any failure -- no rocprofv3, a time-out, a CSV that does not parse -- returns {"error": ...} and the
+    line falls back to the replayed record.  Units and corrections as tools/traffic_from_prof.py: KiB, and on gfx950 FETCH_SIZE
+    tallies 128-byte requests at 64 bytes (doubled here); WRITE_SIZE is exact for 16-byte-per-lane stores."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "no rocprofv3 on this box"}
+    if seed != 42:
+        return {"error": "tools/prof_run.py generates seed 42 only"}
+    gib = n_bytes / GIB
+    sums, counts = {}, {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(root, "tools", "prof_run.py"), "--gib", repr(gib), "--kind", kind, "--only", "both", "--reps", "1"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return {"error": f"{counter} pass: {type(e).__name__}"}
+            if r.returncode != 0 or "prof_run ok" not in r.stdout:
+                return {"error": f"{counter} pass: rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "")
+                    key = "encode" if ("encode_kernel" in name or "encode_small_kernel" in name) else "decode" if "decode_slots_kernel" in name else None
+                    if key and row.get("Counter_Name") == counter:
+                        sums[key, counter] = sums.get((key, counter), 0.0) + float(row["Counter_Value"])
+                        counts[key, counter] = counts.get((key, counter), 0) + 1
+    res = {"source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of tools/prof_run.py behind the timed pass, on this box",
+           "seconds": time.perf_counter() - t0, "fetch_correction": 2.0}
+    for key in ("encode", "decode"):
+        if (key, "FETCH_SIZE") not in sums or (key, "WRITE_SIZE") not in sums:
+            return {"error": f"no {key} kernel rows in the counter files"}
+        f = sums[key, "FETCH_SIZE"] / counts[key, "FETCH_SIZE"] * 1024.0
+        w = sums[key, "WRITE_SIZE"] / counts[key, "WRITE_SIZE"] * 1024.0
+        res[key] = {"fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2.0 * f + w, "launches": counts[key, "FETCH_SIZE"]}
+    return res
+
+
+def apply_live_traffic(result, live):
+    """Puts counters measured in this run into the three coder rooflines and says so in one word (`traffic_from`); the
+    replayed record's issue-side counters (valu_busy, instructions per step) stay where they are, labelled as before."""
+    result["traffic_live"] = live
+    if "error" in live:
+        return False
+    for key, which in (("roofline_encode", "encode"), ("roofline_decode", "decode")):
+        result[key]["traffic"] = live[which]["hbm_bytes_per_launch"]
+        result[key]["traffic_from"] = "live"
+    dom = "decode" if result["roofline"].get("kernel", "").startswith("decode") else "encode"
+    result["roofline"]["traffic"] = live[dom]["hbm_bytes_per_launch"]
+    result["roofline"]["traffic_from"] = "live"
+    return True
+
+
 def usable_cpus():
     """Host CPUs this process may really use: the affinity mask, cut down by the cgroup's CPU quota
     (a container on a 256-thread host is typically given a share of it; os.cpu_count() says 256 anyway)."""
@@ -374,7 +441,9 @@ def annotate_roofs(result, copy_peak, traffic_source=None):
             r["frac_of_measured"] = r["achieved"] / copy_peak["GBps"]
         r["measured_live"] = ("achieved, frac, peak_measured_copy, frac_of_measured (HIP events in this run)"
                               + ("; roofline_valu.shader_clock_measured_MHz (the kernel's own workgroups)" if "roofline_valu" in r else ""))
-        have = [k for k in replayed if r.get(k) is not None]
+        have = [k for k in replayed if r.get(k) is not None and not (k == "traffic" and r.get("traffic_from") == "live")]
+        if r.get("traffic_from") == "live":
+            r["measured_live"] += "; traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs behind the timed pass, on this box)"
         if have:
             r["counters"] = (f"{', '.join(have)}: replayed from profiles/{source} -- rocprofv3 PMC passes cannot run inside "
                              "this process; the record is quoted only while its kernel-source stamp matches the built sources")
@@ -1006,6 +1075,12 @@ def main(argv=None):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:        # at N = 1 only: the other ranks would sit at the barrier
         result["cpu_baseline"] = cpu_baseline(args.kind, args.seed, args.cpu_sample_mib << 20)
+
+    # ---- the coder kernels' HBM bytes measured on THIS box: two rocprofv3 --pmc child runs, N = 1 only, behind everything that
+    #      is timed, this process's buffers freed first ----
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        torch.cuda.empty_cache()
+        apply_live_traffic(result, live_traffic(args.kind, args.seed, n, args.live_traffic_timeout))
 
     if rank == 0:
         print(finish_line(), flush=True)

@@ -744,24 +744,27 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // vector load the whole wavefront waits for (~720 cycles under load, longer than the step) -- the
 // loop below contains neither.  The compiler's own schedule of lane_codec.h's
 // step_symbol spends ~135 slots per symbol (selects for the path bits, s_nop pads behind every lane
-// mask it writes); the statement below spends ~94 vector + 5 LDS.
+// mask it writes); the statements below spend 80 vector + 4.5 LDS (an even step and the odd one behind it: 82 + 4, 78 + 5).
 //
 //   R0 = off*total + total - 1; depths 0 and 1 (registers); READ #1 (mid record) issued
 //       in its shadow: the half of the previous symbol's low record that its path took takes its increments
 //       (one ds_add_u64: count +1, child +1 if left, grandchild +1 if left -- fields stay below 2^14, nothing
-//       carries into a neighbour); register nodes bumped
+//       carries into a neighbour); even step: register nodes bumped, the stream reader's subtraction;
+//       odd step: the stream reader moves on and reads its next dword
 //   wait; mid record: 3 decisions; READ #2 (low record) issued
-//       in its shadow: the mid record's half takes its increments the same way; the stream window steps over the
-//       previous symbol's bits (refill from the LDS ring), peek
-//   wait; low record: 3 decisions, Z for the upper bound; interval narrowed and renormalised;
-//       off = ((off - dn) : window) << n
+//       in its shadow: the mid record's half takes its increments the same way; even step: the stream window's selects and
+//       refill; odd step: register nodes bumped
+//   wait; low record: 3 decisions, the symbol's count for the upper bound; interval narrowed and renormalised;
+//       off = ((off - dn) : window) << n   (which also steps the window over the n bits)
+// What sits in which shadow was settled by timing (profiles/r06_decode_step_budget.txt): since round 6 both waits are worth
+// 3-6 cycles, i.e. the step takes the time its instructions take to issue.
 //
 // Lane masks: v_sub_co writes "went left" as its borrow; v_min keeps the remainder; the mask is
 // read two or more instructions later (path add-with-carry, selects of the next node and of the
 // record update).  The LDS operands need aligned register quads / pairs and the 64-bit shift a
 // pair: they are pinned (v200-v217); everything else is allocated by the compiler.  Both waits have
-// the form "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" (LDS operations of a
-// wavefront complete in order).  Results are those of DecoderLane::step_symbol (same integers), which
+// the form "an LDS read, one LDS operation behind it, s_waitcnt lgkmcnt(1)" -- two and lgkmcnt(2) behind the odd step's
+// first read, which has the stream read behind it as well -- (LDS operations of a wavefront complete in order).  Results are those of DecoderLane::step_symbol (same integers), which
 // the CPU tests pin against the oracle; the GPU parity tests then compare this path with the oracle
 // directly.
 // ---------------------------------------------------------------------------

@@ -314,3 +314,30 @@ def test_watchdog_keeps_stdout_for_the_json_line_only():
             "time.sleep(30)\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=20)
     assert r.returncode == 1 and r.stdout.strip() == '{"metric": 1}'
+
+
+def test_live_traffic_replaces_the_replayed_figure_and_says_so():
+    """the traffic figure of the line is measured on the driver's box when the counter passes succeed ("live"),
+    and the replayed record stays -- labelled "replayed" -- when they do not."""
+    full = bench_stub.full_result(1, "weak")
+    assert full["roofline"]["traffic"] == 18660000000.0
+    live = {"source": "live: ...", "seconds": 41.0, "fetch_correction": 2.0,
+            "encode": {"fetch_size_bytes_raw": 4.3e9, "write_size_bytes": 1.12e10, "hbm_bytes_per_launch": 1.98e10, "launches": 2},
+            "decode": {"fetch_size_bytes_raw": 4.7e9, "write_size_bytes": 8.6e9, "hbm_bytes_per_launch": 1.8e10, "launches": 1}}
+    assert bench.apply_live_traffic(full, live) is True
+    bench.annotate_roofs(full, full["hbm_copy_peak"])
+    d = json.loads(bench.driver_line(full))
+    assert d["roofline"]["traffic"] == 1.8e10 and d["roofline"]["traffic_from"] == "live"
+    assert d["roofline_encode"]["traffic"] == 1.98e10 and d["roofline_encode"]["traffic_from"] == "live"
+    assert "traffic (rocprofv3" in full["roofline"]["measured_live"] and "traffic," not in full["roofline"]["counters"].split(":")[0]
+    assert "valu_busy" in full["roofline"]["counters"]                 # the issue-side counters are still the replayed ones
+    # a failed pass: nothing changes, the reason is kept in the detail object
+    again = bench_stub.full_result(1, "weak")
+    assert bench.apply_live_traffic(again, {"error": "FETCH_SIZE pass: TimeoutExpired"}) is False
+    d = json.loads(bench.driver_line(again))
+    assert d["roofline"]["traffic"] == 18660000000.0 and d["roofline"]["traffic_from"] == "replayed"
+    assert again["traffic_live"]["error"].startswith("FETCH_SIZE")
+    # and with neither: null, no label
+    bare = bench_stub.full_result(1, "weak", traffic={"source": "none"})
+    d = json.loads(bench.driver_line(bare))
+    assert d["roofline"]["traffic"] is None and "traffic_from" not in d["roofline"]

@@ -651,7 +651,7 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, GPUAR_OVERSUBSCRIBE_DEVICES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--gib-per-gpu", "0.25", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json")]
+           "--gib-per-gpu", "0.25", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--no-live-traffic", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d, _ = bench_line_and_detail(r, tmp_path)
@@ -669,7 +669,7 @@ def _self_launched_bench(extra, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json"), *extra]
+           "--no-cpu-baseline", "--no-small-config", "--no-live-traffic", "--detail-file", str(tmp_path / "detail.json"), *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -714,7 +714,7 @@ def test_bench_prints_its_line_when_a_scaling_extra_raises(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(GPUAR_OVERSUBSCRIBE_DEVICES="1", GPUAR_TEST_FAIL_EXTRAS="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gib-per-gpu", "0.125",
-           "--total-gib", "0.25", "--no-cpu-baseline", "--no-small-config", "--extras-timeout", "20", "--detail-file", str(tmp_path / "detail.json")]
+           "--total-gib", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-live-traffic", "--extras-timeout", "20", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
@@ -737,7 +737,7 @@ def test_bench_four_rank_dry_run_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["GPUAR_OVERSUBSCRIBE_DEVICES"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--gib-per-gpu", "0.125", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--detail-file", str(tmp_path / "detail.json")]
+           "--gib-per-gpu", "0.125", "--total-gib", "0.5", "--no-cpu-baseline", "--no-small-config", "--no-live-traffic", "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     line, d = bench_line_and_detail(r, tmp_path)
@@ -764,7 +764,7 @@ def test_rccl_preflight_at_world_size_one(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPUAR_OVERSUBSCRIBE_DEVICES")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collectives", "--steps", "2", "--warmup", "1",
-           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-by-kind", "--init-timeout", "240",
+           "--gib-per-gpu", "0.25", "--no-cpu-baseline", "--no-small-config", "--no-live-traffic", "--no-by-kind", "--init-timeout", "240",
            "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
@@ -813,6 +813,14 @@ def test_bench_line_carries_text_and_zipf_next_to_uniform(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line, d = bench_line_and_detail(r, tmp_path)
     assert set(line["by_kind"]) == {"text", "zipf"} and all(k["ok"] is True and k["frac"] > 0 for k in line["by_kind"].values())
+    # the coder kernels' HBM bytes were MEASURED in this run (two rocprofv3 --pmc child runs behind the timed pass): the line says
+    # "live", and the figure is the algorithmic N + C and a little more, not less and not a multiple
+    assert "error" not in d["traffic_live"], d["traffic_live"]
+    for key in ("roofline", "roofline_encode"):
+        assert line[key]["traffic_from"] == "live", line[key]
+        algo = d[key]["algorithmic_bytes_per_launch"]
+        assert 0.97 * algo < line[key]["traffic"] < 1.6 * algo, (key, line[key]["traffic"], algo)
+    assert d["roofline_decode"]["traffic_from"] == "live" and "traffic (rocprofv3" in d["roofline"]["measured_live"]
     assert abs(line["by_kind"]["text"]["ratio"] - d["by_kind"]["text"]["compression_ratio"]) < 1e-5
     assert d["roofline"]["kernel"] in ("decode_slots_kernel", "encode_kernel") and d["roofline_encode"]["kernel"] == "encode_kernel"
     assert d["collectives"]["through_torch_distributed"] is False
