@@ -1252,6 +1252,23 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 #else
 #define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI) GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)
 #endif
+// (timing experiments only, garbage out: the ring phase without its wait for the vector memory, without its LDS writes, without
+// the multipliers' loads -- profiles/r06_decode_step_budget.txt, section 5)
+#ifdef GPUAR_EXP_NO_RING_VMCNT
+#define GPUAR_RING_VMCNT ""
+#else
+#define GPUAR_RING_VMCNT "s_waitcnt vmcnt(0)\n\t"
+#endif
+#ifdef GPUAR_EXP_NO_RING_WRITES
+#define GPUAR_RING_WRITES(TEXT) ""
+#else
+#define GPUAR_RING_WRITES(TEXT) TEXT
+#endif
+#ifdef GPUAR_EXP_NO_RING_MUL
+#define GPUAR_RING_MUL(TEXT) ""
+#else
+#define GPUAR_RING_MUL(TEXT) TEXT
+#endif
 #define GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)                                                   \
     {                                                                                                                \
         uint32_t t_, t2_;                                                                                            \
@@ -1260,11 +1277,11 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
             "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
             "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
             "v_cmp_gt_u32 vcc, 49, %[t]\n\t" /* (first: the scalar unit reads this mask five instructions later) */  \
-            "s_waitcnt vmcnt(0)\n\t"                                                                                 \
-            "ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                                    \
-            "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t"                                          \
-            "global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[off]\n\t"                                \
-            "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[off]+16\n\t"                             \
+            GPUAR_RING_VMCNT                                                                                         \
+            GPUAR_RING_WRITES("ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                  \
+                              "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t")                        \
+            GPUAR_RING_MUL("global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[off]\n\t"                 \
+                           "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[off]+16\n\t")              \
             "s_and_saveexec_b64 %[sx], vcc\n\t"                                                                      \
             "v_min_u32 %[t], %[fill], %[lastp]\n\t"                                                                  \
             "global_load_dwordx4 v[220:223], %[t], %[base]\n\t"                                                      \
