@@ -38,16 +38,18 @@ others)
     done
     ;;
 bench)
-    timeout -k 10 400 python3 bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+    # the stdout line (<= 4 KB) and, next to it, the full object it was cut out of
+    timeout -k 10 400 python3 bench.py --detail-file "$out/${tag}_bench_detail.json" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
     # the kernel statistics of that very command (a shorter run; TMPDIR for the profiler's scratch files)
     rm -rf "gpurun_out/prof_bench_$tag"
-    ( export TMPDIR=/tmp; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/prof_bench_$tag" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 )
+    ( export TMPDIR=/tmp; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/prof_bench_$tag" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic --detail-file /tmp/bench_detail_under_rocprof.json > /dev/null 2>&1 )
     stats="$(find "gpurun_out/prof_bench_$tag" -name '*kernel_stats.csv' | head -1)"
     [ -n "$stats" ] && cp "$stats" "$out/${tag}_bench_kernel_stats.csv"
     for kind in text zipf; do
-        timeout -k 10 200 python3 bench.py --kind "$kind" --seed 1 --gib-per-gpu 8 --no-cpu-baseline --no-small-config > "$out/${tag}_bench_$kind.json" 2>/dev/null
+        timeout -k 10 200 python3 bench.py --kind "$kind" --seed 1 --gib-per-gpu 8 --no-cpu-baseline --no-small-config --no-by-kind --no-live-traffic \
+            --detail-file "$out/${tag}_bench_${kind}_detail.json" > "$out/${tag}_bench_$kind.json" 2>/dev/null
     done
-    for probe in valu_probe lds_probe ldsbw_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe xlane_probe copy_probe; do
+    for probe in valu_probe lds_probe ldsbw_probe placement_probe lat_probe stride_probe active_probe mix_probe halfexec_probe xlane_probe copy_probe latsearch_probe; do
         [ -x "tools/$probe.bin" ] && timeout -k 10 200 "./tools/$probe.bin" > "$out/${tag}_$probe.txt" 2>&1
     done
     [ -x tools/io_probe.bin ] && timeout -k 10 200 ./tools/io_probe.bin /tmp 2 > "$out/${tag}_io_probe.txt" 2>&1
