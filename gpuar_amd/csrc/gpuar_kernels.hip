@@ -37,6 +37,12 @@
 
 #include "lane_codec.h"
 
+// The GPUAR_EXP_* switches below take pieces OUT of the kernels to price them (profiles/r0N_*budget*.txt, *attribution*.txt): such a
+// build produces WRONG output.  It only compiles when the build says it is one (tools/exp_build.sh defines GPUAR_EXPERIMENT_BUILD for
+// any flag of that family), and the library then says so in gpuar_hip_version(), which gpuar_amd/hip.py refuses to load as the product.
+#if (defined(GPUAR_EXP_NO_ADDS) || defined(GPUAR_EXP_NO_CODER) || defined(GPUAR_EXP_NO_LOW) || defined(GPUAR_EXP_NO_READS) || defined(GPUAR_EXP_NO_RING) || defined(GPUAR_EXP_NO_RING_MUL) || defined(GPUAR_EXP_NO_RING_VMCNT) || defined(GPUAR_EXP_NO_RING_WRITES) || defined(GPUAR_EXP_NO_SEARCH) || defined(GPUAR_EXP_NO_STORES) || defined(GPUAR_EXP_NO_STREAM) || defined(GPUAR_EXP_NO_STREAM_READ) || defined(GPUAR_EXP_NO_WAIT1) || defined(GPUAR_EXP_NO_WAIT2)) && !defined(GPUAR_EXPERIMENT_BUILD)
+#error "a GPUAR_EXP_* switch without GPUAR_EXPERIMENT_BUILD: these builds decode / encode garbage; use tools/exp_build.sh"
+#endif
 namespace gpuar {
 
 __constant__ RecipTable g_recip = RecipTable();
@@ -734,7 +740,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // The symbol step of the decoder, scheduled by hand for a wavefront that is ALONE on its SIMD
 // (the per-packet model pins 36 KiB of LDS per wavefront, four wavefronts per CU).
 //
-// What tools/lat_probe.hip measures for such a wavefront (profiles/r02_lat_probe.txt): every vector
+// What tools/lat_probe.hip measures for such a wavefront (profiles/archive/r02_lat_probe.txt): every vector
 // instruction costs one issue slot of 4.2-4.7 cycles whether or not it depends on its predecessor;
 // `s_nop 0` costs a whole slot (4 cycles), `s_nop 1` two; a scalar instruction costs a slot as well;
 // ds_read_b128 comes back after ~65 cycles and holds the issue port ~12, ds_write_b128 ~20.  So the
@@ -774,7 +780,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 
 // One symbol of the hand-scheduled decoder (see above), in text pieces.  The step forms the whole 64-bit increment of
 // its low half itself, in v204:v205, and the NEXT step applies it with one ds_add_u64 in the shadow of its first LDS read
-// (profiles/r03_decode_cost_attribution.txt: an LDS add costs this wavefront ~20 cycles to issue, a ds_write_b64 ~28, and
+// (profiles/archive/r03_decode_cost_attribution.txt: an LDS add costs this wavefront ~20 cycles to issue, a ds_write_b64 ~28, and
 // the four vector instructions that used to rebuild the half's two dwords are gone; WAITED for, an LDS atomic is 60-440
 // cycles dearer than a write, tools/lat_probe.hip).  One more instruction of a step waits for that shadow: clearing the
 // top bit of lo (an instruction behind an LDS operation's issue costs this wavefront less than one in the chain; a variant
@@ -1817,7 +1823,11 @@ const char *gpuar_hip_error_string(int code) {
     }
 }
 
+#ifdef GPUAR_EXPERIMENT_BUILD
+const char *gpuar_hip_version(void) { return "gpuar-hip 0.2 gfx950 EXPERIMENT BUILD (timing switches: output may be garbage)"; }
+#else
 const char *gpuar_hip_version(void) { return "gpuar-hip 0.2 gfx950"; }
+#endif
 
 int gpuar_hip_abi_version(void) { return GPUAR_HIP_ABI_VERSION; }
 

@@ -324,9 +324,6 @@ struct PartialModeler {
     }
 
     uint32_t next_tag;                      // row tag of the symbol whose nodes are held in left[] (the next to account)
-#ifdef GPUAR_EXP_TOP_PAD
-    uint32_t pad = 1;
-#endif
 
   private:
     // z: path bits of x | path bits of x + 1, kShift bits up; kAhead: fetch the nodes of the symbol tagged xn behind the stores
@@ -362,27 +359,11 @@ struct PartialModeler {
             half0 += quarter == 0u ? 1u : 0u;
             half1 += quarter == 2u ? 1u : 0u;
         }
-#if defined(GPUAR_EXP_TOP_PAD) && defined(__HIP_DEVICE_COMPILE__)      // (timing experiments only: dummy vector instructions in the top modeler's step)
-        if (kFirst <= 2 && !kTail) {
-#pragma unroll
-            for (int d = 0; d < GPUAR_EXP_TOP_PAD; ++d) asm volatile("v_mad_u32_u24 %0, %0, 1, 0" : "+v"(pad));
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < kDepths; ++k) {
             const uint32_t pick = (z >> (kShift + 7 - (kFirst + k))) & 0x10001u;
             const uint32_t l = left[k];
             acc = GPUAR_MAD24(l, pick, acc);
-#if defined(GPUAR_EXP_TOP_ATOMIC) && defined(__HIP_DEVICE_COMPILE__)   // (timing experiments only, WRONG output: one LDS add-with-return per level
-            if (kFirst <= 2 && !kTail) {                               // in the top modeler instead of read + write, at no extra vector instruction)
-                if (kAhead) {
-                    where[k] = tree.node(xn, kFirst + k);
-                    const uint32_t lds_at = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(where[k])) & ~3u;    // (the low half of a generic LDS pointer is the LDS address)
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(left[k]) : "v"(lds_at), "v"(pick) : "memory");
-                }
-                continue;
-            }
-#endif
             *where[k] = static_cast<uint16_t>(GPUAR_XOR1_ADD(pick, l));   // +1 where x goes left
             if (kAhead) {
                 where[k] = tree.node(xn, kFirst + k);
@@ -403,10 +384,10 @@ struct PartialModeler {
 #ifndef GPUAR_TOP_DEPTHS
 #define GPUAR_TOP_DEPTHS 4          // LDS-resident depths the top modeler walks (1 .. GPUAR_TOP_DEPTHS); the low modeler takes the rest
 #endif
-#ifdef GPUAR_EXP_TOP_SKIP_D1        // (timing experiments only, WRONG output: nobody walks depth 1 -- what taking it out of the top modeler's LDS stream could buy at most)
-template <uint32_t kRowShift>
-using TopModeler = PartialModeler<kRowShift, 2, GPUAR_TOP_DEPTHS - 1, 0, false>;
-#elif defined(GPUAR_TOP_D1_REGS)    // depth 1 in a register of the top modeler, depths 2 .. GPUAR_TOP_DEPTHS in LDS
+// (Round 5's timing experiments on this stream -- dummy instructions in the top modeler's step, an LDS add-with-return per level,
+// depth 1 walked by nobody: profiles/r05_encoder_attribution.txt -- produced WRONG output and are no longer in this header, which the
+// host build shares; they are in the history at cfd435d.)
+#if defined(GPUAR_TOP_D1_REGS)    // depth 1 in a register of the top modeler, depths 2 .. GPUAR_TOP_DEPTHS in LDS
 template <uint32_t kRowShift>
 using TopModeler = PartialModeler<kRowShift, 2, GPUAR_TOP_DEPTHS - 1, 3, false>;
 #else

@@ -44,6 +44,11 @@ def load() -> C.CDLL:
         raise GpuarError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    # a library built from older sources lacks newer exports: say "rebuild" instead of dying with an AttributeError half-way
+    # through the declarations below
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise GpuarError(f"{LIB_PATH} lacks {missing}: it was built from older sources -- rebuild the library")
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     lib.initConstantRange.restype = None
     lib.initConstantRange.argtypes = []
@@ -81,6 +86,10 @@ def load() -> C.CDLL:
     lib.gpuar_hip_clock_samples.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
     if lib.gpuar_hip_abi_version() != ABI_VERSION:
         raise GpuarError(f"{LIB_PATH} speaks ABI {lib.gpuar_hip_abi_version()}, these bindings {ABI_VERSION}: rebuild the library")
+    # a build with timing switches (tools/exp_build.sh -DGPUAR_EXP_...) decodes / encodes garbage by design: it is loaded only from
+    # where the timing tools put it (LIB_PATH pointed there by --lib), never as the product library
+    if b"EXPERIMENT" in lib.gpuar_hip_version() and os.path.abspath(LIB_PATH) == os.path.join(_HERE, "lib", "libgpuar_hip.so"):
+        raise GpuarError(f"{LIB_PATH} is an experiment build ({lib.gpuar_hip_version().decode()}): rebuild the product library with make")
     _lib = lib
     return lib
 

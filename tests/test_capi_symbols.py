@@ -105,3 +105,21 @@ def test_header_layout_helper():
     assert len(h) == 20 and h[0:3] == b"\x00\x01\x00"
     assert int.from_bytes(h[4:8], "little") == 65539
     assert int.from_bytes(h[12:16], "little") == 66087
+
+
+def test_the_product_library_is_not_an_experiment_build():
+    """The GPUAR_EXP_* timing switches take pieces out of the kernels (WRONG output by design).  Such a build only compiles with
+    GPUAR_EXPERIMENT_BUILD (tools/exp_build.sh), says so in its version string, and gpuar_amd/hip.py refuses it as the product."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "gpuar_amd", "lib", "libgpuar_hip.so"))
+    lib.gpuar_hip_version.restype = C.c_char_p
+    assert b"EXPERIMENT" not in lib.gpuar_hip_version()
+    src = open(os.path.join(root, "gpuar_amd", "csrc", "gpuar_kernels.hip")).read()
+    guard = src[src.index("#if (defined(GPUAR_EXP_"):src.index('#error "a GPUAR_EXP_* switch without GPUAR_EXPERIMENT_BUILD')]
+    switches = set(re.findall(r"GPUAR_EXP_[A-Z0-9_]+", src)) - {"GPUAR_EXP_STORES"}
+    assert switches and all(f"defined({s})" in guard for s in switches), sorted(switches)     # every switch is under the guard
+    # the header the host build shares carries no wrong-output branch at all
+    assert "GPUAR_EXP_" not in open(os.path.join(root, "gpuar_amd", "csrc", "lane_codec.h")).read().replace("GPUAR_EXP_* ", "")
+    assert "GPUAR_EXPERIMENT_BUILD" in open(os.path.join(root, "tools", "exp_build.sh")).read()

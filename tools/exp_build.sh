@@ -11,9 +11,12 @@ out="$root/gpuar_amd/lib/exp/$1.so"
 mkdir -p "$root/gpuar_amd/lib/exp" "$root/build"
 rm -f "$out"
 [ -f "$root/build/host_codec.o" ] || make -C "$root/gpuar_amd/csrc" "$root/build/host_codec.o" > /dev/null || exit 1
+# a timing switch of the GPUAR_EXP_* family takes pieces out of a kernel: the build must say that it is an experiment
+marker=""
+case "${2:-}" in *GPUAR_EXP_*) marker="-DGPUAR_EXPERIMENT_BUILD=1" ;; esac
 log="$(mktemp)"
 ( cd "$root/gpuar_amd/csrc" && "$hipcc" --offload-arch="$arch" -O3 -std=c++17 -fPIC -I"$root/include" -Wno-unused-function \
-    -mllvm -phi-node-folding-threshold=64 -mllvm -two-entry-phi-node-folding-threshold=64 ${2:-} -shared \
+    -mllvm -phi-node-folding-threshold=64 -mllvm -two-entry-phi-node-folding-threshold=64 ${2:-} $marker -shared \
     -o "$out" "$root/build/host_codec.o" gpuar_kernels.hip ) > "$log" 2>&1
 rc=$?
 grep -E "error|warning: v" "$log"
