@@ -153,7 +153,8 @@ int gpuar_hip_last_error(void);
 
 const char *gpuar_hip_error_string(int code);
 
-/* Build identification, e.g. "gpuar-hip 0.2 gfx950". */
+/* Build identification, e.g. "gpuar-hip 0.2 gfx950".  A library built with timing switches (GPUAR_EXP_*: pieces of the kernels left
+ * out to price them, WRONG output by design) says "... EXPERIMENT BUILD ..." here. */
 const char *gpuar_hip_version(void);
 
 /* The number of this header's ABI, GPUAR_HIP_ABI_VERSION at the time the library was built.  It changes whenever
