@@ -515,6 +515,57 @@ def test_packets_that_keep_carrying_against_oracle(H, oracle, encode_mode):
     assert H.status() == 0
 
 
+def test_packets_that_drain_the_stream_window_fast_against_oracle(H, oracle):
+    """The decoder refills its stream window every SECOND symbol and asks for ring pieces by where its reader stands
+    (gpuar_kernels.hip, "the stream reader", "the stream ring"): both rest on a symbol taking at most 16 stream bits.  These
+    packets make lanes run at the top of that for thousands of symbols while their neighbours idle: a model trained on one
+    byte (or on a few) and then fed bytes it has never seen -- 12-13 bits a symbol --, switch points and lengths ragged, next to
+    constant packets (0.2 bits a symbol) and uniform ones (8).  Slots against the oracle; both decoders back to the bytes."""
+    rng = np.random.default_rng(6006)
+    npk = 192
+    data = np.zeros(npk * 8192, dtype=np.uint8)
+    for p in range(npk):
+        view = data[p * 8192:(p + 1) * 8192]
+        kind = p % 6
+        if kind == 0:                                       # one byte for a while, then every other byte in turn
+            cut = int(rng.integers(512, 7000))
+            view[:cut] = rng.integers(0, 256)
+            view[cut:] = (np.arange(8192 - cut) * 37 + int(rng.integers(0, 256))).astype(np.uint8)
+        elif kind == 1:                                     # a few bytes, then bytes drawn from the unseen rest, then back
+            few = rng.integers(0, 256, 3).astype(np.uint8)
+            a, b = sorted(int(v) for v in rng.integers(256, 7900, 2))
+            view[:] = rng.choice(few, 8192)
+            rest = np.setdiff1d(np.arange(256, dtype=np.uint8), few)
+            view[a:b] = rng.choice(rest, b - a)
+        elif kind == 2:
+            view[:] = rng.integers(0, 256)                  # constant: the slowest reader
+        elif kind == 3:
+            view[:] = rng.integers(0, 256, 8192)            # uniform
+        elif kind == 4:                                     # bursts of rare bytes in a constant packet
+            view[:] = 0x20
+            for _ in range(int(rng.integers(1, 40))):
+                at = int(rng.integers(0, 8100))
+                view[at:at + int(rng.integers(1, 90))] = rng.integers(0, 256, 1)
+        else:                                               # a ramp over all byte values, then a constant tail
+            cut = int(rng.integers(300, 8000))
+            view[:cut] = (np.arange(cut) % 256).astype(np.uint8)
+            view[cut:] = 0xFF
+    n = npk * 8192 - 777
+    data = data[:n]
+    want, want_len, total = oracle_slots(oracle, data)
+    assert 7500 < want_len.max() <= 8704                      # some packets really are long, none outgrows its slot
+    d_slots = H.encode(torch.from_numpy(data).cuda())
+    got = d_slots.cpu().numpy().reshape(npk, 8704)
+    got_len = got[:, 0].astype(np.int64) | (got[:, 1].astype(np.int64) << 8)
+    assert np.array_equal(want_len, got_len)
+    mask = np.arange(8704)[None, :] < want_len[:, None]
+    assert np.array_equal(got[mask], want[mask])
+    assert np.array_equal(H.decode(d_slots, npk).cpu().numpy()[:n], data)
+    d_stream, d_off = H.compact(d_slots, npk)
+    assert np.array_equal(H.decode_stream(d_stream, d_off, npk).cpu().numpy()[:n], data)
+    assert H.status() == 0
+
+
 @pytest.mark.parametrize("seed", [7, 8])
 def test_round_trips_over_ten_source_models(H, oracle, seed, encode_mode):
     """4096 packets from ten source models -- uniform, few symbols, geometric, runs, ramps, midpoint pairs, a constant with
