@@ -804,10 +804,28 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #else
 #define GPUAR_LDS_STREAM_READ(TEXT) TEXT
 #endif
+// The model's total (256 + position, the same in every lane) reaches the step as a VECTOR register that the step itself counts up in
+// an LDS shadow (round 6b).  Rounds 2-6a passed it as a scalar operand, which the compiler formed by one s_or per statement right in
+// front of the step's first instruction -- on the chain, and a scalar instruction costs a lone wavefront a slot like any other.
+#define GPUAR_HEAD_R0 \
+            "v_mul_u32_u24_sdwa %[R0], %[off], %[totv]" GPUAR_SDWA_W0 /* off = the low half of lo : off */
+#define GPUAR_HEAD_R0_ADD \
+            "v_add3_u32 %[R0], %[R0], %[totv], -1\n\t" /* off*total + total - 1 */
+#define GPUAR_TOTAL_STEP "v_add_u32 %[totv], 1, %[totv]\n\t"
+#ifndef GPUAR_DEC_TOTAL_PLACE
+#define GPUAR_DEC_TOTAL_PLACE 1          /* (A/B: 1 = counted up in the first LDS shadow, 2 = in the second; the same) */
+#endif
+#if GPUAR_DEC_TOTAL_PLACE == 1
+#define GPUAR_TOTAL_STEP_EARLY GPUAR_TOTAL_STEP
+#define GPUAR_TOTAL_STEP_LATE ""
+#else
+#define GPUAR_TOTAL_STEP_EARLY ""
+#define GPUAR_TOTAL_STEP_LATE GPUAR_TOTAL_STEP
+#endif
 #define GPUAR_A_HEAD \
-            "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 /* off = the low half of lo : off */ \
+            GPUAR_HEAD_R0 \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
-            "v_add3_u32 %[R0], %[R0], %[tbase], %[tj]\n\t" /* off*total + total - 1: total - 1 = (the run's first total - 1) + position, an inline constant */ \
+            GPUAR_HEAD_R0_ADD \
             "v_sub_co_u32 %[t1], %[m0], %[R0], %[t0]\n\t" /* borrow = went left at depth 0 */ \
             "v_min_u32 %[R], %[R0], %[t1]\n\t" \
             "v_cndmask_b32 %[t2], %[h1], %[h0], %[m0]\n\t" /* the depth-1 node on the path */ \
@@ -920,7 +938,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // or left to the next step's first shadow (empty; GPUAR_A_SHADOW_DEFERRED)
 #define GPUAR_LOW_ADDRESS_NOW \
             "v_lshl_add_u32 %[oaddr], %[c6], 9, %[collow]\n\t" /* the low half that takes the increments (in the next step's shadow) */
-#define GPUAR_BC_LOW(OWN_ADDRESS) GPUAR_BC_LOW_WALK_TEXT(OWN_ADDRESS) GPUAR_BC_LOW_INTERVAL
+#define GPUAR_BC_LOW(OWN_ADDRESS, MUL) GPUAR_BC_LOW_WALK_TEXT(OWN_ADDRESS) GPUAR_BC_LOW_INTERVAL(MUL)
 #define GPUAR_BC_LOW_WALK_TEXT(OWN_ADDRESS) \
             GPUAR_WAIT2 /* read #2 is back (behind it: the mid half's LDS add, perhaps the stream reader's dword) */ \
          /* ---- low record: v212 = aR | bR << 16, v213 = cRR | cRL << 16 (right half), v214 = a | bL << 16, v215 = cLR | cLL << 16 (left half). \
@@ -952,12 +970,12 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_sub_u32 %[t3], %[ps], %[t2]\n\t" /* the right leaf */ \
             "v_min_u32 %[R], %[R], %[t1]\n\t" \
             "v_cndmask_b32 %[t3], %[t3], %[t2], vcc\n\t" /* cnt(symbol) */
-#define GPUAR_BC_LOW_INTERVAL \
+#define GPUAR_BC_LOW_INTERVAL(MUL) /* MUL: the name of the operand that holds this symbol's reciprocal multiplier */ \
          /* ---- applySymbolRange (:256-299) and the renormalisation (:787-836) */ \
             "v_sub_u32 %[t0], %[R0], %[R]\n\t" /* cumLo * range */ \
             "v_mad_u32_u24 %[t1], %[t3], %[rng], %[t0]\n\t" /* cumHi * range = cumLo * range + cnt * range */ \
-            "v_mul_hi_u32 %[dn], %[t0], %[mul]\n\t" \
-            "v_mul_hi_u32 %[t1], %[t1], %[mul]\n\t" \
+            "v_mul_hi_u32 %[dn], %[t0], %[" MUL "]\n\t" \
+            "v_mul_hi_u32 %[t1], %[t1], %[" MUL "]\n\t" \
             "v_lshrrev_b32 %[dn], %[shift], %[dn]\n\t" \
             "v_lshrrev_b32 %[t1], %[shift], %[t1]\n\t" \
             "v_mad_u32_u24 v217, %[dn], %[kffff], v217\n\t" /* lo : off -> (lo + dn) : (off - dn) in one: + dn * 0xFFFF (dn <= off, lo + dn < 2^16) */ \
@@ -972,16 +990,16 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // The end of the step: the grandchild's increment sits between the SDWA write of kff and its reader; the last instruction
 // but one files the symbol: all eight complemented path bits = 2 * (the first seven) + the last decision's borrow, written
 // straight into byte J of the output word (SDWA dst_sel, the other bytes preserved) -- no shift-or per symbol.
-#define GPUAR_BC_LOW_END \
+#define GPUAR_BC_LOW_END(N) /* N: the name of the operand this step leaves its bit count in ("ne" in an even step, "no" in an odd one) */ \
             "v_cndmask_b32 v205, 0, %[ti], vcc\n\t" \
             "v_lshlrev_b32 %[t2], %[e], %[kff]\n\t" \
             "v_lshrrev_b32 %[t2], 31, %[t2]\n\t" \
-            "v_add3_u32 %[n], %[e], %[t2], -1\n\t" \
-            "v_lshlrev_b32 %[rng], %[n], %[wd]\n\t"
+            "v_add3_u32 %[" N "], %[e], %[t2], -1\n\t" \
+            "v_lshlrev_b32 %[rng], %[" N "], %[wd]\n\t"
 // (not the statement's very last instruction: what reads the word behind the statement is the compiler's, and it does
 // not know that the word was written by halves)
-#define GPUAR_FILE_SYMBOL(J) \
-            "v_addc_co_u32_sdwa %[word], vcc, %[c7], %[c7], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+#define GPUAR_FILE_SYMBOL(J, WORD) \
+            "v_addc_co_u32_sdwa %[" WORD "], vcc, %[c7], %[c7], vcc dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
 // The stream reader.  What a step needs of the stream is the window v216: the next stream bits, left-aligned, of which the
 // 64-bit shift at the end of the step (GPUAR_OFF_TEXT) moves the top n <= 16 into lo : off -- and leaves v216 = window << n,
@@ -1005,7 +1023,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // 25.8; the even step's subtraction moved to its first shadow 25.6; the odd step's part in ITS first shadow as well 25.2-25.3
 // (kept); everything in first shadows 25.7.  A shadow hides three or four instructions, not ten.
 #define GPUAR_STREAM_PART_A \
-            "v_add_u32 %[pc], %[nprev], %[n]\n\t" /* the bits of the two symbols since the last refill: <= 32 */ \
+            "v_add_u32 %[pc], %[no], %[ne]\n\t" /* the bits of the two symbols since the last refill: <= 32 */ \
             "v_sub_co_u32 %[raw], %[sb], %[rem], %[pc]\n\t" /* borrow: w0 ran out */ \
             "v_and_b32 %[rem], 31, %[raw]\n\t"
 #define GPUAR_STREAM_PART_B \
@@ -1079,8 +1097,8 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 // <= width << n = range' <= 2^16 keeps the lower half inside its 16 bits; bit 31 is the last underflow position
 // (lo' = (a << n) & 0x7FFF) and is cleared in the NEXT step's LDS shadow (GPUAR_A_SHADOW; decode_wave clears it once
 // more behind the last step).
-#define GPUAR_OFF_TEXT \
-            "v_lshlrev_b64 v[216:217], %[n], v[216:217]\n\t"
+#define GPUAR_OFF_TEXT(N) \
+            "v_lshlrev_b64 v[216:217], %[" N "], v[216:217]\n\t"
 
 #define GPUAR_STEP_OPERANDS_COMMON \
               [R0] "=&v"(R0), [R] "=&v"(R), [np] "=&v"(np), [am] "=&v"(am), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), \
@@ -1095,50 +1113,40 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
         uint32_t R0, R, np, am, t0, t1, t2, t3, dn, bw, cc, pa, pb, pc, ps, wd, h, e; \
         unsigned long long m0, m1, ma, mc, mj, sx, sb;
 
-// TEXT: the step's instruction text (one of the kinds below); WORD: the output word the symbol is filed in; N: where this
-// step leaves the number of stream bits it took (even and odd steps have a register each: the even step's refill needs both)
-// and N_PREV the other one
-#define GPUAR_DECODE_STATEMENT(TEXT, K_TOTAL, K_TOTAL0_M1, POS, K_MUL, K_SHIFT, WORD, N, N_PREV) \
-    { \
-        GPUAR_STEP_LOCALS \
-        uint32_t lbw_, lcc_, ti_, path7_; \
-        unsigned long long lma_; \
-        asm volatile(TEXT \
-            : GPUAR_STEP_OPERANDS_COMMON, \
-              [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [word] "+v"(WORD), "+v"(o0), "+v"(o1), \
-              [c6] "+v"(path6), [c7] "=&v"(path7_), [n] "+v"(N) \
-            : [nprev] "v"(N_PREV), [tot] "s"((K_TOTAL)), [mul] "v"((K_MUL)), [shift] "s"((K_SHIFT)), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds), \
-              [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), [tbase] "s"((K_TOTAL0_M1)), [tj] "n"(POS) \
-            : "vcc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215"); \
-    }
 // The kinds of step in a loop body of 32 symbols.  By position: all but the last leave the address of their low half to the next
 // step's first LDS shadow (the path after six decisions stays in a register of its own, `path6`), all but the first form it
 // there for their predecessor.  By parity: even steps refill the stream window, odd steps live on what the even one left.
+// J: the byte of its output word the step files its symbol in; MUL, WORD: the NAMES of the operands that hold the symbol's
+// reciprocal multiplier and its output word (a run of eight steps is ONE asm statement, below); the step leaves the number of stream
+// bits it took in "ne" (even steps) or "no" (odd steps): the even step's refill needs both.
+#define GPUAR_N_EVEN "ne"
+#define GPUAR_N_ODD "no"
 #ifdef GPUAR_EXP_NO_SEARCH      /* (timing experiments only, garbage out: the step WITHOUT its symbol search -- no decision, no record read, no
                                    increment, no register-node update: what every decoder of this format pays per symbol whatever finds the symbol,
                                    profiles/r06_latency_decoder_prototype.txt) */
-#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J) \
-            "v_mul_u32_u24_sdwa %[R0], %[off], %[tot]" GPUAR_SDWA_W0 \
-            "v_add3_u32 %[R0], %[R0], %[tbase], %[tj]\n\t" \
+#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J, MUL, WORD) \
+            GPUAR_HEAD_R0 GPUAR_HEAD_R0_ADD GPUAR_TOTAL_STEP \
             "v_lshrrev_b32 %[R], 1, %[R0]\n\t" \
             "v_mov_b32 %[t3], 1\n\t" \
             "v_mov_b32 %[c7], %[c6]\n\t" \
-            GPUAR_STREAM_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_TEXT GPUAR_BC_LOW_INTERVAL GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+            GPUAR_STREAM_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_TEXT GPUAR_BC_LOW_INTERVAL(MUL) GPUAR_BC_LOW_END(GPUAR_N_##PARITY) \
+            GPUAR_FILE_SYMBOL(J, WORD) GPUAR_OFF_TEXT(GPUAR_N_##PARITY)
 #else
-#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J) \
-    GPUAR_A_HEAD SHADOW GPUAR_NODES_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_EARLY GPUAR_BC_MID(GPUAR_WAIT1_GPUAR_STREAM_##PARITY##_EARLY) \
-    GPUAR_STREAM_##PARITY##_TEXT GPUAR_NODES_##PARITY##_LATE GPUAR_BC_LOW(OWN_ADDRESS) GPUAR_BC_LOW_END GPUAR_FILE_SYMBOL(J) GPUAR_OFF_TEXT
+#define GPUAR_STEP_TEXT(SHADOW, PARITY, OWN_ADDRESS, J, MUL, WORD) \
+    GPUAR_A_HEAD SHADOW GPUAR_TOTAL_STEP_EARLY GPUAR_NODES_##PARITY##_EARLY GPUAR_STREAM_##PARITY##_EARLY GPUAR_BC_MID(GPUAR_WAIT1_GPUAR_STREAM_##PARITY##_EARLY) \
+    GPUAR_STREAM_##PARITY##_TEXT GPUAR_NODES_##PARITY##_LATE GPUAR_TOTAL_STEP_LATE GPUAR_BC_LOW(OWN_ADDRESS, MUL) GPUAR_BC_LOW_END(GPUAR_N_##PARITY) \
+    GPUAR_FILE_SYMBOL(J, WORD) GPUAR_OFF_TEXT(GPUAR_N_##PARITY)
 #endif
 #ifdef GPUAR_DEC_NO_DEFER      /* (A/B builds: every step forms its own address, as in rounds 2-4a) */
-#define GPUAR_STEP_FIRST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, GPUAR_LOW_ADDRESS_NOW, J)
-#define GPUAR_STEP_EVEN(J) GPUAR_STEP_FIRST(J)
-#define GPUAR_STEP_ODD(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, ODD, GPUAR_LOW_ADDRESS_NOW, J)
-#define GPUAR_STEP_LAST(J) GPUAR_STEP_ODD(J)
+#define GPUAR_STEP_FIRST(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, GPUAR_LOW_ADDRESS_NOW, J, MUL, WORD)
+#define GPUAR_STEP_EVEN(J, MUL, WORD) GPUAR_STEP_FIRST(J, MUL, WORD)
+#define GPUAR_STEP_ODD(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, ODD, GPUAR_LOW_ADDRESS_NOW, J, MUL, WORD)
+#define GPUAR_STEP_LAST(J, MUL, WORD) GPUAR_STEP_ODD(J, MUL, WORD)
 #else
-#define GPUAR_STEP_FIRST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, , J)
-#define GPUAR_STEP_EVEN(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, EVEN, , J)
-#define GPUAR_STEP_ODD(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, , J)
-#define GPUAR_STEP_LAST(J) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, GPUAR_LOW_ADDRESS_NOW, J)
+#define GPUAR_STEP_FIRST(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_PLAIN, EVEN, , J, MUL, WORD)
+#define GPUAR_STEP_EVEN(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, EVEN, , J, MUL, WORD)
+#define GPUAR_STEP_ODD(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, , J, MUL, WORD)
+#define GPUAR_STEP_LAST(J, MUL, WORD) GPUAR_STEP_TEXT(GPUAR_A_SHADOW_DEFERRED, ODD, GPUAR_LOW_ADDRESS_NOW, J, MUL, WORD)
 #endif
 
 // LDS of a decoder workgroup (one wavefront): the 64 models and the 64 stream rings, 40 KiB -> four per CU.
@@ -1179,6 +1187,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     // the stream bits the last two symbols took and the reader has not stepped over yet: the even step's and the odd step's, a
     // register each (GPUAR_STREAM_EVEN_EARLY takes both off `rem` at once)
     uint32_t n_even = 0, n_odd = dec.owed_bits;
+    uint32_t total_v = 256u;                   // the model's total as a vector register (the same in every lane): GPUAR_TOTAL_STEP
     uint32_t rem_raw = 0;                      // the even step's `rem` before it was wrapped into 0..31: negative where w0 ran out -- the odd step
                                                // behind it moves those lanes' reader on (a vector register: nothing crosses statements as a lane mask)
     register uint32_t window asm("v216");      // the stream bits in front of the reader, left-aligned: filled by every even step, shifted
@@ -1253,13 +1262,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 // knows them as the pinned variables m<SET>0..7) -- where the step's two v_mul_hi_u32 take it from directly.  The
 // loads land before the next phase's s_waitcnt vmcnt(0), one whole run before they are used.  (Rounds 2-3 kept symbol j's
 // multiplier in lane j of ONE register per block of 64 and fetched it with a v_readlane per symbol.)
-#ifdef GPUAR_EXP_NO_RING        /* (timing experiments only, garbage out: no ring phase at all) */
-#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI)
-#else
-#define GPUAR_RING_PHASE(OFF, SET, TUPLE_LO, TUPLE_HI) GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)
-#endif
 // (timing experiments only, garbage out: the ring phase without its wait for the vector memory, without its LDS writes, without
-// the multipliers' loads -- profiles/r06_decode_step_budget.txt, section 5)
+// the multipliers' loads -- profiles/r06_decode_step_budget.txt, section 3b)
 #ifdef GPUAR_EXP_NO_RING_VMCNT
 #define GPUAR_RING_VMCNT ""
 #else
@@ -1275,33 +1279,27 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
 #else
 #define GPUAR_RING_MUL(TEXT) TEXT
 #endif
-#define GPUAR_RING_PHASE_TEXT(OFF, SET, TUPLE_LO, TUPLE_HI)                                                   \
-    {                                                                                                                \
-        uint32_t t_, t2_;                                                                                            \
-        unsigned long long sx_;                                                                                      \
-        asm volatile(                                                                                                \
-            "v_lshrrev_b32 %[t], 6, %[next]\n\t"                                                                     \
-            "v_sub_u32 %[t], %[fill], %[t]\n\t"                                                                      \
-            "v_cmp_gt_u32 vcc, 49, %[t]\n\t" /* (first: the scalar unit reads this mask five instructions later) */  \
+// (the phase is the tail of its run's asm statement -- GPUAR_DECODE_RUN8 --: it shares the run's operands `next`, `ring`, `t2`, `sx`)
+#ifdef GPUAR_EXP_NO_RING        /* (timing experiments only, garbage out: no ring phase at all) */
+#define GPUAR_RING_PHASE_TEXT(TUPLE_LO, TUPLE_HI) ""
+#else
+#define GPUAR_RING_PHASE_TEXT(TUPLE_LO, TUPLE_HI)                                                                    \
+            "v_lshrrev_b32 %[rt], 6, %[next]\n\t"                                                                    \
+            "v_sub_u32 %[rt], %[fill], %[rt]\n\t"                                                                    \
+            "v_cmp_gt_u32 vcc, 49, %[rt]\n\t" /* (first: the scalar unit reads this mask five instructions later) */ \
             GPUAR_RING_VMCNT                                                                                         \
             GPUAR_RING_WRITES("ds_write2st64_b32 %[slot], v220, v221 offset1:1\n\t"                                  \
                               "ds_write2st64_b32 %[slot], v222, v223 offset0:2 offset1:3\n\t")                        \
-            GPUAR_RING_MUL("global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[off]\n\t"                 \
-                           "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[off]+16\n\t")              \
+            GPUAR_RING_MUL("global_load_dwordx4 " TUPLE_LO ", %[zero], %[mulbase] offset:%[roff]\n\t"                \
+                           "global_load_dwordx4 " TUPLE_HI ", %[zero], %[mulbase] offset:%[roff]+16\n\t")              \
             "s_and_saveexec_b64 %[sx], vcc\n\t"                                                                      \
-            "v_min_u32 %[t], %[fill], %[lastp]\n\t"                                                                  \
-            "global_load_dwordx4 v[220:223], %[t], %[base]\n\t"                                                      \
+            "v_min_u32 %[rt], %[fill], %[lastp]\n\t"                                                                 \
+            "global_load_dwordx4 v[220:223], %[rt], %[base]\n\t"                                                     \
             "v_and_b32 %[t2], 48, %[fill]\n\t"                                                                       \
             "v_lshl_add_u32 %[slot], %[t2], 6, %[ring]\n\t"                                                          \
             "v_add_u32 %[fill], 16, %[fill]\n\t"                                                                     \
-            "s_or_b64 exec, exec, %[sx]"                                                                             \
-            : [slot] "+v"(slot_lds), [fill] "+v"(fill), [t] "=&v"(t_), [t2] "=&v"(t2_), [sx] "=&s"(sx_),             \
-              "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "=v"(m##SET##0), "=v"(m##SET##1), "=v"(m##SET##2), "=v"(m##SET##3), \
-              "=v"(m##SET##4), "=v"(m##SET##5), "=v"(m##SET##6), "=v"(m##SET##7)                                     \
-            : [next] "v"(next64), [lastp] "v"(last_piece), [base] "s"(base16), [ring] "v"(ring_lds),                 \
-              [zero] "v"(vzero), [mulbase] "s"(mul_base), [off] "n"(OFF)                                             \
-            : "vcc", "memory");                                                                                      \
-    }
+            "s_or_b64 exec, exec, %[sx]"
+#endif
 
     // The per-symbol reciprocal multipliers (wave-uniform) reach the symbol step WITHOUT scalar loads and -- since round 4 --
     // without a v_readlane: the ring phase above fetches the eight of the run after next into registers by vector loads
@@ -1321,23 +1319,35 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     register uint32_t m30 asm("v248"); register uint32_t m31 asm("v249"); register uint32_t m32 asm("v250"); register uint32_t m33 asm("v251"); register uint32_t m34 asm("v252"); register uint32_t m35 asm("v253"); register uint32_t m36 asm("v254"); register uint32_t m37 asm("v255");
     uint32_t vzero;                                             // (a zero the compiler does not know: the loads' vector offset)
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-// Eight symbols (two output words) and the ring phase behind them; RUN (0..3) is the run's static position in the half block.
+// Eight symbols (two output words) and the ring phase behind them, as ONE asm statement; RUN (0..3) is the run's static position
+// in the half block.  (Rounds 2-6a: a statement per symbol.  Between two statements the compiler puts what it likes -- the s_or
+// that formed the symbol's total, the halves of an s_add_u32 / s_addc_u32 pair, a wait state for a store hazard the statement
+// next door cannot have -- and every scalar instruction or s_nop there is a slot on the chain: 24.9 -> 24.4 ms for the total as a
+// self-counting vector register, and the rest with the statements joined.)
+// scc is clobbered: s_and_b64 / s_andn2_b64 / s_and_saveexec_b64 / s_or_b64 write it, and the compiler DOES keep a carry alive
+// across a statement when it has such a pair to spread (a build without the per-statement s_or faulted on exactly that).
 #define GPUAR_DECODE_RUN8(RUN, FIRST_KIND, LAST_KIND, WORD_A, WORD_B, SET_AHEAD, TUPLE_LO, TUPLE_HI)                         \
         {                                                                                                            \
-            const uint32_t j0 = 32u * half + 8u * (RUN); /* wave-uniform: first symbol of this run inside the block */ \
-            const uint32_t total0 = 256u + i + j0;                                                                   \
-            const uint32_t total0_m1 = 255u + i + j0; /* each step adds its position in the run as an inline constant */ \
-            /* every symbol goes into its own byte of its word */                                                    \
-            GPUAR_DECODE_STATEMENT(FIRST_KIND(0), total0, total0_m1, 0, m##RUN##0, block_shift, WORD_A, n_even, n_odd)                  \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(1), total0 + 1u, total0_m1, 1, m##RUN##1, block_shift, WORD_A, n_odd, n_even)        \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(2), total0 + 2u, total0_m1, 2, m##RUN##2, block_shift, WORD_A, n_even, n_odd)       \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(3), total0 + 3u, total0_m1, 3, m##RUN##3, block_shift, WORD_A, n_odd, n_even)        \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(0), total0 + 4u, total0_m1, 4, m##RUN##4, block_shift, WORD_B, n_even, n_odd)       \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_ODD(1), total0 + 5u, total0_m1, 5, m##RUN##5, block_shift, WORD_B, n_odd, n_even)        \
-            GPUAR_DECODE_STATEMENT(GPUAR_STEP_EVEN(2), total0 + 6u, total0_m1, 6, m##RUN##6, block_shift, WORD_B, n_even, n_odd)       \
-            GPUAR_DECODE_STATEMENT(LAST_KIND(3), total0 + 7u, total0_m1, 7, m##RUN##7, block_shift, WORD_B, n_odd, n_even)             \
-            /* ... and fetches the multipliers of the run after next: 8 * (RUN + 2) dwords behind the half block's first */ \
-            GPUAR_RING_PHASE(32 * ((RUN) + 2), SET_AHEAD, TUPLE_LO, TUPLE_HI)                                        \
+            GPUAR_STEP_LOCALS                                                                                        \
+            uint32_t lbw_, lcc_, ti_, path7_, rt_;                                                                   \
+            unsigned long long lma_;                                                                                 \
+            asm volatile(                                                                                            \
+                FIRST_KIND(0, "mul0", "wa") GPUAR_STEP_ODD(1, "mul1", "wa") GPUAR_STEP_EVEN(2, "mul2", "wa") GPUAR_STEP_ODD(3, "mul3", "wa") \
+                GPUAR_STEP_EVEN(0, "mul4", "wb") GPUAR_STEP_ODD(1, "mul5", "wb") GPUAR_STEP_EVEN(2, "mul6", "wb") LAST_KIND(3, "mul7", "wb") \
+                /* ... and the phase fetches the multipliers of the run after next: 8 * (RUN + 2) dwords behind the half block's first */ \
+                GPUAR_RING_PHASE_TEXT(TUPLE_LO, TUPLE_HI)                                                            \
+                : GPUAR_STEP_OPERANDS_COMMON,                                                                        \
+                  [lbw] "=&v"(lbw_), [lcc] "=&v"(lcc_), [ti] "=&v"(ti_), [lma] "=&s"(lma_), [wa] "+v"(WORD_A), [wb] "+v"(WORD_B),     \
+                  "+v"(o0), "+v"(o1), [c6] "+v"(path6), [c7] "=&v"(path7_), [ne] "+v"(n_even), [no] "+v"(n_odd), [totv] "+v"(total_v), \
+                  [slot] "+v"(slot_lds), [fill] "+v"(fill), [rt] "=&v"(rt_), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3),               \
+                  "=v"(m##SET_AHEAD##0), "=v"(m##SET_AHEAD##1), "=v"(m##SET_AHEAD##2), "=v"(m##SET_AHEAD##3),                     \
+                  "=v"(m##SET_AHEAD##4), "=v"(m##SET_AHEAD##5), "=v"(m##SET_AHEAD##6), "=v"(m##SET_AHEAD##7)                      \
+                : [mul0] "v"(m##RUN##0), [mul1] "v"(m##RUN##1), [mul2] "v"(m##RUN##2), [mul3] "v"(m##RUN##3),                     \
+                  [mul4] "v"(m##RUN##4), [mul5] "v"(m##RUN##5), [mul6] "v"(m##RUN##6), [mul7] "v"(m##RUN##7),                     \
+                  [shift] "s"(block_shift), [col] "v"(col_lds), [collow] "v"(col_low_lds), [ring] "v"(ring_lds),                  \
+                  [k64k] "v"(k64k), [k64k1] "v"(k64k1), [bsw] "s"(bswap_sel), [kf00] "s"(ring_wrap), [km32k] "s"(minus_half), [kffff] "s"(low_half), \
+                  [lastp] "v"(last_piece), [base] "s"(base16), [zero] "v"(vzero), [mulbase] "s"(mul_base), [roff] "n"(32 * ((RUN) + 2))   \
+                : "vcc", "scc", "memory", "v200", "v201", "v202", "v203", "v208", "v209", "v212", "v213", "v214", "v215");         \
         }
 // A block of 64 symbols as two half blocks of 32: the loop body is 32 symbols long, so every output word has a register
 // of its own by name -- rounds 1-3 looped over runs of eight and filed each word into a register array by index (a
@@ -1352,6 +1362,8 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     {                                                                                                                \
         /* the shift that goes with the multipliers: floor(log2(total)) - 1, the same for all 64 totals of a block */ \
         const uint32_t block_shift = 30u - static_cast<uint32_t>(__builtin_clz(256u + i));                           \
+        total_v = 256u + i; /* the model's total at the block's first symbol; every step counts it up */              \
+        asm volatile("" : "+v"(total_v));                                                                            \
         _Pragma("unroll 1") for (uint32_t half = 0; half < 2u; ++half) {                                             \
             const uint32_t *mul_base = g_mul.m + i + 32u * half; /* wave-uniform: a scalar pair */                  \
             /* what a step leaves to the next one's first shadow: the path after six decisions (written by every step of   */ \
@@ -1408,7 +1420,7 @@ __device__ __forceinline__ void decode_wave(uint8_t *col, uint8_t *ring, const u
     }
 #undef GPUAR_DECODE_BLOCK
 #undef GPUAR_DECODE_RUN8
-#undef GPUAR_RING_PHASE
+
 #undef GPUAR_RING_PHASE_TEXT
     // hand the state back to the plain step (the tail below, finish()); `ahead` may still be on its way from the ring
     // (and a piece the last ring phase asked for may still be on its way into v220-v223)

@@ -458,7 +458,8 @@ struct CoderLane {
                 "v_and_b32 %[acc], %[bits], %[tm]\n\t"
                 "s_or_b64 exec, exec, %[sx]"
                 : [at] "+v"(at), [acc] "+v"(acc), [ta] "=&v"(t_addr), [tw] "=&v"(t_word), [tm] "=&v"(t_mask), [sx] "=&s"(saved)
-                : [m] "s"(full), [last] "v"(last), [word] "v"(word), [sel] "s"(0x00010203u), [base] "s"(base), [total] "v"(total), [bits] "v"(bits));
+                : [m] "s"(full), [last] "v"(last), [word] "v"(word), [sel] "s"(0x00010203u), [base] "s"(base), [total] "v"(total), [bits] "v"(bits)
+                : "scc", "memory");       // (s_and_saveexec_b64 / s_or_b64 write scc; the region stores)
         }
 #else
         acc = (acc << (count & 31u)) | bits;                    // right if nothing leaves

@@ -2,7 +2,7 @@
 ROCm LLVM tools are missing).
 
 DESIGN.md's speed rests on facts no parity test sees: 39 936 / 40 960 bytes of LDS per workgroup (exactly four per CU),
-no scratch, no spills, the 82 / 78-instruction hand-scheduled symbol steps of the decoder, registers pinned by name
+no scratch, no spills, the 83 / 79-instruction hand-scheduled symbol steps of the decoder, registers pinned by name
 (v220-v255) that the compiler must leave alone.  A toolchain bump that re-pads, spills or halves the occupancy would keep
 every parity test green; it must fail HERE, not in a bench.  (The reference fixes its occupancy by hand too --
 32-thread blocks and 16.5 KB of shared memory per block, /root/reference/src/gpu.h:9 --; here it is a derived fact.)
@@ -155,8 +155,12 @@ def step_regions(text):
 @pytest.mark.parametrize("kernel", ["decode_slots_kernel", "decode_stream_kernel"])
 def test_decoder_symbol_step_keeps_its_instruction_budget(code_object, kernel):
     """The hand-scheduled step: an EVEN step -- which refills the stream window for itself and its successor, in
-    all lanes alike -- is 82 vector + 4 LDS instructions, the ODD one behind it -- which moves the reader on and reads the next
-    stream dword -- 78 + 5: 80 + 4.5 per symbol (rounds 4-5: 82 + 5, and two scalar instructions that wrote exec).  Exactly two waits, each for
+    all lanes alike -- is 83 vector + 4 LDS instructions, the ODD one behind it -- which moves the reader on and reads the next
+    stream dword -- 79 + 5: 81 + 4.5 per symbol, the model's total counted up by one of them (rounds 4-5: 82 + 5, two scalar
+    instructions that wrote exec and an s_or per symbol for the total).  A run of eight steps is ONE asm statement: between two
+    steps of a run there is NOTHING -- no s_nop, no scalar bookkeeping of the compiler's (a scalar instruction costs a lone
+    wavefront a slot like any other) --, and inside a step the only scalar instructions are the two lane-mask combinations of the
+    depth-1 register nodes and the two waits.  Exactly two waits, each for
     a record read with one LDS operation behind it (lgkmcnt(1)) or -- the odd step's first, which has the stream read behind it too -- two
     (lgkmcnt(2)), no vector memory instruction, no s_nop
     pad, no branch, and NOTHING that writes exec inside a step.  Two loop bodies of 32 steps per kernel (the wave-uniform one
@@ -174,17 +178,24 @@ def test_decoder_symbol_step_keeps_its_instruction_budget(code_object, kernel):
     middle = {k: v for k, v in shapes.items() if k[3] == 0 and k[5] == 0}          # steps without a ring phase or a loop edge behind them
     assert sum(middle.values()) >= 54, shapes
     for (valu, ds, waits, vmem, nops, branches), count in middle.items():
-        assert (valu, ds) in ((78, 5), (79, 5), (82, 4), (83, 4)) and waits == 2 and nops == 0, ((valu, ds, waits, vmem, nops, branches), count)
+        assert (valu, ds) in ((79, 5), (80, 5), (83, 4), (84, 4)) and waits == 2 and nops == 0, ((valu, ds, waits, vmem, nops, branches), count)
     two = shapes.most_common(2)
-    assert {k[:3] for k, _ in two} == {(78, 5, 2), (82, 4, 2)} and min(c for _, c in two) >= 20, shapes
-    # per symbol (an even step and the odd one behind it): 80 vector and 4.5 LDS instructions
-    assert sum(k[0] for k, _ in two) == 160 and sum(k[1] for k, _ in two) == 9, two
+    assert {k[:3] for k, _ in two} == {(79, 5, 2), (83, 4, 2)} and min(c for _, c in two) >= 20, shapes
+    # per symbol (an even step and the odd one behind it): 81 vector and 4.5 LDS instructions
+    assert sum(k[0] for k, _ in two) == 162 and sum(k[1] for k, _ in two) == 9, two
+    # scalar instructions of a plain step: s_and_b64 + s_andn2_b64 (the register nodes' lane masks) and the two waits, nothing else
+    for r in regions:
+        ops = [t.split()[0] for t in r]
+        if any(o.startswith(("global_", "flat_", "s_cbranch", "s_branch")) for o in ops):
+            continue
+        scalar = sorted(o for o in ops if o.startswith("s_"))
+        assert scalar == ["s_and_b64", "s_andn2_b64", "s_waitcnt", "s_waitcnt"], scalar
     # the (even) steps behind a ring phase carry it in their region: seven vector instructions, two LDS writes, up to three loads, one more wait; where the compiler's own
     # scalar bookkeeping for the next run meets the phase's first instruction it may need one wait state (an s_nop 0 in a
     # slot a scalar instruction would take anyway) -- one, not a pad per lane mask as in the compiler's own schedule of the step
     for (valu, ds, waits, vmem, nops, branches), count in shapes.items():
         if branches == 0:
-            assert nops <= (1 if vmem else 0) and valu <= 93 and ds <= 7 and vmem <= 3, (valu, ds, waits, vmem, nops)
+            assert nops <= (1 if vmem else 0) and valu <= 94 and ds <= 7 and vmem <= 3, (valu, ds, waits, vmem, nops)
     # the window refill is selects on a lane mask now: inside a plain step nothing writes exec (the ring phase still does)
     for r in regions:
         if not any(t.split()[0].startswith(("global_", "flat_")) for t in r):
