@@ -822,6 +822,18 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
 #define GPUAR_TOTAL_STEP_EARLY ""
 #define GPUAR_TOTAL_STEP_LATE GPUAR_TOTAL_STEP
 #endif
+// A record read goes out as soon as its address is there: the remainder's minimum behind the decision in front of it (which the
+// address does not need) is taken in the read's shadow (round 6b: 24.06 -> 23.87 ms; GPUAR_DEC_MIN_EARLY=1: in front of the read, as
+// in rounds 2-6a).  The step's time is the vector instructions OUTSIDE the two LDS round trips + the round trips: both shadows are
+// full (moving the instruction that files the symbol into the next step's first shadow changed nothing: 23.82 / 23.83 against
+// 23.82 / 23.85), so only what shortens the stretch in front of a read still pays.
+#ifdef GPUAR_DEC_MIN_EARLY
+#define GPUAR_MIN_BEFORE_READ(TEXT) TEXT
+#define GPUAR_MIN_BEHIND_READ(TEXT) ""
+#else
+#define GPUAR_MIN_BEFORE_READ(TEXT) ""
+#define GPUAR_MIN_BEHIND_READ(TEXT) TEXT
+#endif
 #define GPUAR_A_HEAD \
             GPUAR_HEAD_R0 \
             "v_mul_u32_u24 %[t0], %[root], %[rng]\n\t" \
@@ -831,11 +843,12 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_cndmask_b32 %[t2], %[h1], %[h0], %[m0]\n\t" /* the depth-1 node on the path */ \
             "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[m1], %[R], %[t0]\n\t" \
-            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            GPUAR_MIN_BEFORE_READ("v_min_u32 %[R], %[R], %[t1]\n\t") \
             "v_cndmask_b32 %[np], 0, 2, %[m0]\n\t" \
             "v_addc_co_u32 %[np], vcc, %[np], 0, %[m1]\n\t" /* complemented top two symbol bits */ \
             "v_lshl_add_u32 %[am], %[np], 10, %[col]\n\t" \
             GPUAR_LDS_READ("ds_read2_b64 v[200:203], %[am] offset1:64\n\t") /* READ #1: mid record, right half -> v200:201, left half -> v202:203 */ \
+            GPUAR_MIN_BEHIND_READ("v_min_u32 %[R], %[R], %[t1]\n\t") /* (the remainder behind the second decision: the record's address does not need it) */ \
 
 #define GPUAR_A_SHADOW_PLAIN \
          /* in its shadow: the half of the PREVIOUS symbol's low record its path went through takes its increments by ONE \
@@ -899,6 +912,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_addc_co_u32 %[t3], %[mj], %[t3], %[t3], %[mc]\n\t" \
             "v_lshl_add_u32 %[oaddr], %[t3], 10, %[collow]\n\t" \
             GPUAR_LDS_READ("ds_read2_b64 v[212:215], %[oaddr] offset1:64\n\t") /* READ #2: low record */ \
+            GPUAR_MIN_BEHIND_READ("v_min_u32 %[R], %[R], %[t1]\n\t") \
          /* ---- the mid half takes its increments by one 64-bit LDS add in the shadow of read #2 */ \
             "v_lshl_add_u32 %[am], %[np], 9, %[col]\n\t" /* where that half lives: its index is the path up to the record's first decision */ \
             "v_cndmask_b32 v208, 1, %[k64k1], vcc\n\t" /* +1 on the half's count, +1 for bL/bR if left at the middle decision */ \
@@ -930,7 +944,7 @@ encode_small_kernel(const uint8_t *__restrict__ src, size_t size, uint8_t *__res
             "v_cndmask_b32_sdwa %[t2], %[cc], %[cc], vcc" GPUAR_SDWA_HALVES \
             "v_mul_u32_u24 %[t0], %[t2], %[rng]\n\t" \
             "v_sub_co_u32 %[t1], %[mc], %[R], %[t0]\n\t" \
-            "v_min_u32 %[R], %[R], %[t1]\n\t" \
+            GPUAR_MIN_BEFORE_READ("v_min_u32 %[R], %[R], %[t1]\n\t") \
             "v_addc_co_u32 %[t3], %[mj], %[np], %[np], vcc\n\t" \
             GPUAR_MID_WRITEBACK
 
