@@ -743,7 +743,6 @@ def driver_line(result, detail_name=DETAIL_FILE):
     s = g("small_config")
     if isinstance(s, dict):
         line["small_config"] = {"mib": 64, "encode_GBps": _r(s.get("encode_GBps")), "decode_GBps": _r(s.get("decode_GBps")),
-                                "decode_mode": s.get("decode_mode"),
                                 "md5_match": s.get("stream_md5") == s.get("reference_stream_md5"), "roundtrip_equal": s.get("roundtrip_equal")}
     if g("n_gpus", 1) > 1 and isinstance(g("per_rank"), dict):
         line["per_rank"] = {k: _r(v) for k, v in g("per_rank").items() if not isinstance(v, (list, dict))}
