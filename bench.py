@@ -248,11 +248,15 @@ def load_profiled_traffic(kind, n_bytes, root=ROOT, stamp=None):
     return {"source": "; ".join(why[:3])}
 
 
+LIVE_PASSES = (("FETCH_SIZE", "GRBM_GUI_ACTIVE"), ("WRITE_SIZE",),
+               ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS"))
+
+
 def live_traffic(kind, seed, n_bytes, timeout_s, root=ROOT):
-    """HBM bytes per launch of the two coder kernels, MEASURED ON THIS BOX in this run: two fresh child processes,
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/prof_run.py ...` and the same with WRITE_SIZE (the two counters do
-    not fit one pass, /opt/skills/guides/MI355X_MICROARCH.md), on the same stream kind and size as the timed pass, after it and
-    with its buffers freed.  The program itself follows `--` (no shell, no env, no exec of this GPU-holding process); each pass
+    """HBM bytes per launch of the two coder kernels -- and their issue-side counters -- MEASURED ON THIS BOX in this run: fresh
+    child processes `rocprofv3 --kernel-trace --pmc <counters> -- python3 tools/prof_run.py ...`, one per entry of LIVE_PASSES
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass, /opt/skills/guides/MI355X_MICROARCH.md; the SQ counters are a third; the third
+    may fail without costing the first two), on the same stream kind and size as the timed pass, after it and with its buffers freed.  The program itself follows `--` (no shell, no env, no exec of this GPU-holding process); each pass
     has its own timer and any failure -- no rocprofv3, a time-out, a CSV that does not parse -- returns {"error": ...} and the
     line falls back to the replayed record.  Units and corrections as tools/traffic_from_prof.py: KiB, and on gfx950 FETCH_SIZE
     tallies 128-byte requests at 64 bytes (doubled here); WRITE_SIZE is exact for 16-byte-per-lane stores."""
@@ -269,46 +273,78 @@ def live_traffic(kind, seed, n_bytes, timeout_s, root=ROOT):
     sums, counts = {}, {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(d, counter)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+        issue_error = None
+        for n_pass, counters in enumerate(LIVE_PASSES):
+            out = os.path.join(d, f"pass{n_pass}")
+            cmd = [prof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.join(root, "tools", "prof_run.py"), "--gib", repr(gib), "--kind", kind, "--only", "both", "--reps", "1"]
+            why = None
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+                if r.returncode != 0 or "prof_run ok" not in r.stdout:
+                    why = f"{counters[0]} pass: rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"
             except (subprocess.TimeoutExpired, OSError) as e:
-                return {"error": f"{counter} pass: {type(e).__name__}"}
-            if r.returncode != 0 or "prof_run ok" not in r.stdout:
-                return {"error": f"{counter} pass: rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
+                why = f"{counters[0]} pass: {type(e).__name__}"
+            if why:
+                if n_pass < 2:
+                    return {"error": why}
+                issue_error = why                     # the traffic passes are in: the line quotes them, and says what became of this one
+                break
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row.get("Kernel_Name", "")
                     key = "encode" if ("encode_kernel" in name or "encode_small_kernel" in name) else "decode" if "decode_slots_kernel" in name else None
-                    if key and row.get("Counter_Name") == counter:
+                    counter = row.get("Counter_Name")
+                    if key and counter in counters:
                         sums[key, counter] = sums.get((key, counter), 0.0) + float(row["Counter_Value"])
                         counts[key, counter] = counts.get((key, counter), 0) + 1
-    res = {"source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of tools/prof_run.py behind the timed pass, on this box",
-           "seconds": time.perf_counter() - t0, "fetch_correction": 2.0}
+    res = {"source": "live: rocprofv3 --pmc child runs of tools/prof_run.py (FETCH_SIZE + GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_*) behind the timed "
+                     "pass, on this box", "seconds": time.perf_counter() - t0, "fetch_correction": 2.0, "n_bytes": n_bytes}
+    if issue_error:
+        res["issue_counters_error"] = issue_error
+    symbol_steps = n_bytes / 64.0                       # one step = 64 lanes x one byte each
     for key in ("encode", "decode"):
         if (key, "FETCH_SIZE") not in sums or (key, "WRITE_SIZE") not in sums:
             return {"error": f"no {key} kernel rows in the counter files"}
-        f = sums[key, "FETCH_SIZE"] / counts[key, "FETCH_SIZE"] * 1024.0
-        w = sums[key, "WRITE_SIZE"] / counts[key, "WRITE_SIZE"] * 1024.0
+        avg = lambda c, key=key: sums[key, c] / counts[key, c]          # noqa: E731
+        f, w = avg("FETCH_SIZE") * 1024.0, avg("WRITE_SIZE") * 1024.0
         res[key] = {"fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2.0 * f + w, "launches": counts[key, "FETCH_SIZE"]}
+        if (key, "SQ_INSTS_VALU") in sums:              # the same derivations as tools/traffic_from_prof.py
+            res[key].update({"valu_insts_per_symbol_step": avg("SQ_INSTS_VALU") / symbol_steps,
+                             "lds_insts_per_symbol_step": avg("SQ_INSTS_LDS") / symbol_steps,
+                             "valu_busy": avg("SQ_ACTIVE_INST_VALU") / avg("SQ_WAVE_CYCLES"),
+                             "wait_frac": avg("SQ_WAIT_ANY") / avg("SQ_WAVE_CYCLES")})
+            if (key, "GRBM_GUI_ACTIVE") in sums:        # (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; SQ_* are in quad-cycles)
+                res[key]["valu_busy_per_simd"] = avg("SQ_ACTIVE_INST_VALU") * 4.0 / (avg("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
     return res
 
 
-def apply_live_traffic(result, live):
-    """Puts counters measured in this run into the three coder rooflines and says so in one word (`traffic_from`); the
-    replayed record's issue-side counters (valu_busy, instructions per step) stay where they are, labelled as before."""
+ISSUE_COUNTERS = ("valu_insts_per_symbol_step", "lds_insts_per_symbol_step", "valu_busy", "valu_busy_per_simd", "wait_frac")
+
+
+def apply_live_traffic(result, live, machine=None):
+    """Puts counters measured in this run into the three coder rooflines and says so in one word each (`traffic_from`,
+    `counters_from`): HBM bytes always, the issue-side counters (instructions per symbol step, vector-pipe busy, wait share) and
+    the vector roof made of them when the third pass came in; what did not come in stays the replayed record's, labelled as before."""
     result["traffic_live"] = live
     if "error" in live:
         return False
-    for key, which in (("roofline_encode", "encode"), ("roofline_decode", "decode")):
-        result[key]["traffic"] = live[which]["hbm_bytes_per_launch"]
-        result[key]["traffic_from"] = "live"
     dom = "decode" if result["roofline"].get("kernel", "").startswith("decode") else "encode"
-    result["roofline"]["traffic"] = live[dom]["hbm_bytes_per_launch"]
-    result["roofline"]["traffic_from"] = "live"
+    for key, which in (("roofline_encode", "encode"), ("roofline_decode", "decode"), ("roofline", dom)):
+        r, got = result[key], live[which]
+        r["traffic"], r["traffic_from"] = got["hbm_bytes_per_launch"], "live"
+        if "valu_insts_per_symbol_step" in got:
+            for k in ISSUE_COUNTERS:
+                if k in got:
+                    r[k] = got[k]
+            r["counters_from"] = "live"
+            old = r.get("roofline_valu") or {}
+            ms = r["algorithmic_bytes_per_launch"] / (r["achieved"] * 1e9) * 1e3          # the launch time the HBM figure was made of
+            n_bytes = live.get("n_bytes")
+            if n_bytes:
+                r["roofline_valu"] = valu_roof(got["valu_insts_per_symbol_step"], n_bytes, ms,
+                                               measured_mhz=old.get("shader_clock_measured_MHz") or r.get("shader_clock_measured_MHz"), **(machine or {}))
+                r["roofline_valu"]["lane_ops_per_byte_from"] = "SQ_INSTS_VALU per symbol step of a wavefront (64 lanes, 64 bytes), counted in this run"
     return True
 
 
@@ -441,7 +477,10 @@ def annotate_roofs(result, copy_peak, traffic_source=None):
             r["frac_of_measured"] = r["achieved"] / copy_peak["GBps"]
         r["measured_live"] = ("achieved, frac, peak_measured_copy, frac_of_measured (HIP events in this run)"
                               + ("; roofline_valu.shader_clock_measured_MHz (the kernel's own workgroups)" if "roofline_valu" in r else ""))
-        have = [k for k in replayed if r.get(k) is not None and not (k == "traffic" and r.get("traffic_from") == "live")]
+        have = [k for k in replayed if r.get(k) is not None and not (k == "traffic" and r.get("traffic_from") == "live")
+                and not (k != "traffic" and r.get("counters_from") == "live")]
+        if r.get("counters_from") == "live":
+            r["measured_live"] += "; instructions per symbol step, vector-pipe busy, wait share and the vector roof made of them (a third --pmc pass)"
         if r.get("traffic_from") == "live":
             r["measured_live"] += "; traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs behind the timed pass, on this box)"
         if have:
@@ -700,6 +739,8 @@ def _slim_roof(r):
     for k in ("valu_busy_per_simd", "wait_frac"):
         if r.get(k) is not None:
             out[k] = _r(r[k], 3)
+    if out.get("valu_insts_per_step") is not None or out.get("valu_busy_per_simd") is not None:
+        out["counters_from"] = r.get("counters_from", "replayed")
     return out
 
 
@@ -1079,7 +1120,7 @@ def main(argv=None):
     #      is timed, this process's buffers freed first ----
     if rank == 0 and world == 1 and not args.no_live_traffic:
         torch.cuda.empty_cache()
-        apply_live_traffic(result, live_traffic(args.kind, args.seed, n, args.live_traffic_timeout))
+        apply_live_traffic(result, live_traffic(args.kind, args.seed, n, args.live_traffic_timeout), machine)
 
     if rank == 0:
         print(finish_line(), flush=True)

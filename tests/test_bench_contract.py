@@ -321,7 +321,7 @@ def test_live_traffic_replaces_the_replayed_figure_and_says_so():
     and the replayed record stays -- labelled "replayed" -- when they do not."""
     full = bench_stub.full_result(1, "weak")
     assert full["roofline"]["traffic"] == 18660000000.0
-    live = {"source": "live: ...", "seconds": 41.0, "fetch_correction": 2.0,
+    live = {"source": "live: ...", "seconds": 41.0, "fetch_correction": 2.0, "n_bytes": 8 * GIB,
             "encode": {"fetch_size_bytes_raw": 4.3e9, "write_size_bytes": 1.12e10, "hbm_bytes_per_launch": 1.98e10, "launches": 2},
             "decode": {"fetch_size_bytes_raw": 4.7e9, "write_size_bytes": 8.6e9, "hbm_bytes_per_launch": 1.8e10, "launches": 1}}
     assert bench.apply_live_traffic(full, live) is True
@@ -330,7 +330,24 @@ def test_live_traffic_replaces_the_replayed_figure_and_says_so():
     assert d["roofline"]["traffic"] == 1.8e10 and d["roofline"]["traffic_from"] == "live"
     assert d["roofline_encode"]["traffic"] == 1.98e10 and d["roofline_encode"]["traffic_from"] == "live"
     assert "traffic (rocprofv3" in full["roofline"]["measured_live"] and "traffic," not in full["roofline"]["counters"].split(":")[0]
-    assert "valu_busy" in full["roofline"]["counters"]                 # the issue-side counters are still the replayed ones
+    assert "valu_busy" in full["roofline"]["counters"]                 # only two passes came in: the issue-side counters are the replayed ones
+    assert d["roofline"]["counters_from"] == "replayed" and d["roofline"]["valu_insts_per_step"] == 83.25
+    # all three passes: instructions per step, vector-pipe busy and the vector roof are this run's as well
+    third = bench_stub.full_result(1, "weak")
+    live3 = json.loads(json.dumps(live))
+    live3["decode"].update({"valu_insts_per_symbol_step": 82.27, "lds_insts_per_symbol_step": 4.77, "valu_busy": 0.76, "valu_busy_per_simd": 0.757, "wait_frac": 0.115})
+    live3["encode"].update({"valu_insts_per_symbol_step": 77.94, "lds_insts_per_symbol_step": 16.9, "valu_busy": 0.24, "valu_busy_per_simd": 0.943, "wait_frac": 0.5})
+    assert bench.apply_live_traffic(third, live3) is True
+    bench.annotate_roofs(third, third["hbm_copy_peak"])
+    d3 = json.loads(bench.driver_line(third))
+    r = d3["roofline"]
+    assert r["counters_from"] == "live" and r["valu_insts_per_step"] == 82.27 and r["valu_busy_per_simd"] == 0.757 and r["wait_frac"] == 0.115
+    ms = third["roofline"]["algorithmic_bytes_per_launch"] / (third["roofline"]["achieved"] * 1e9) * 1e3
+    want = 82.27 * 8 * GIB / (ms * 1e-3) / (256 * 4 * 16 * 2391.654321e6)       # against the clock the kernel's workgroups measured (the stub's)
+    assert abs(r["valu_frac"] - want) < 1e-4, (r["valu_frac"], want)
+    assert third["roofline"]["counters"].startswith("none quoted") or "replayed" not in third["roofline"]["counters"].split(":")[0]
+    assert "a third --pmc pass" in third["roofline"]["measured_live"] and d3["roofline_encode"]["counters_from"] == "live"
+    assert len(bench.driver_line(third)) <= bench.LINE_LIMIT
     # a failed pass: nothing changes, the reason is kept in the detail object
     again = bench_stub.full_result(1, "weak")
     assert bench.apply_live_traffic(again, {"error": "FETCH_SIZE pass: TimeoutExpired"}) is False

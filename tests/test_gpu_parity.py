@@ -872,6 +872,11 @@ def test_bench_line_carries_text_and_zipf_next_to_uniform(tmp_path):
         algo = d[key]["algorithmic_bytes_per_launch"]
         assert 0.97 * algo < line[key]["traffic"] < 1.6 * algo, (key, line[key]["traffic"], algo)
     assert d["roofline_decode"]["traffic_from"] == "live" and "traffic (rocprofv3" in d["roofline"]["measured_live"]
+    # ... and so were the issue-side counters (the third pass): instructions per symbol step and the vector pipe's share
+    assert "issue_counters_error" not in d["traffic_live"], d["traffic_live"]
+    assert line["roofline"]["counters_from"] == "live" and line["roofline_encode"]["counters_from"] == "live"
+    assert 70 < line["roofline_encode"]["valu_insts_per_step"] < 90 and 70 < d["roofline_decode"]["valu_insts_per_symbol_step"] < 95
+    assert 0.3 < d["roofline_decode"]["roofline_valu"]["frac"] < 1.0 and 0.5 < line["roofline_encode"]["valu_frac"] < 1.05
     assert abs(line["by_kind"]["text"]["ratio"] - d["by_kind"]["text"]["compression_ratio"]) < 1e-5
     assert d["roofline"]["kernel"] in ("decode_slots_kernel", "encode_kernel") and d["roofline_encode"]["kernel"] == "encode_kernel"
     assert d["collectives"]["through_torch_distributed"] is False
